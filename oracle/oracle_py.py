@@ -1,0 +1,151 @@
+"""ORACLE -- TEST INFRASTRUCTURE.  ctypes face of oracle/_build/liboracle.so.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  Never the
+product package.  Build with `make -C oracle` (or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "_build", "liboracle.so")
+
+
+class OracleCamera(C.Structure):
+    _fields_ = [(n, C.c_double * 3) for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")] + \
+               [("lens_radius", C.c_double), ("time1", C.c_double), ("time2", C.c_double)]
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("samples_per_pixel", C.c_int32),
+                ("max_depth", C.c_int32), ("threads", C.c_int32), ("row_chunk_compat", C.c_int32),
+                ("seed", C.c_uint64), ("bvh_seed", C.c_uint64), ("background", C.c_double * 3)]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("box_tests", "sphere_tests", "moving_sphere_tests", "rect_tests",
+                                          "triangle_tests", "scatters", "texels", "perlin_calls", "rays", "samples")]
+
+
+_D = C.POINTER(C.c_double)
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("oracle library %s missing: run `make -C oracle`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.oracle_o1_render.restype = C.c_int
+    lib.oracle_o1_render.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OracleCamera), C.POINTER(OracleConfig), _D, C.POINTER(C.c_uint8)]
+    lib.oracle_o2_render.restype = C.c_int
+    lib.oracle_o2_render.argtypes = [C.c_void_p, C.POINTER(OracleCamera), C.POINTER(OracleConfig), C.c_int32, C.c_int32,
+                                     C.c_int32, _D, C.POINTER(C.c_uint8), C.POINTER(OracleCounters)]
+    lib.oracle_o2_sample.restype = C.c_int
+    lib.oracle_o2_sample.argtypes = [C.c_void_p, C.POINTER(OracleCamera), C.POINTER(OracleConfig), C.c_int32, C.c_int32, C.c_int32, _D]
+    lib.oracle_o1_vec3_ops.restype = None
+    lib.oracle_o1_vec3_ops.argtypes = [_D, _D, C.c_double, _D]
+    lib.oracle_o1_tone_map.restype = None
+    lib.oracle_o1_tone_map.argtypes = [_D, C.c_uint32, C.POINTER(C.c_int32)]
+    lib.oracle_o1_sphere_uv.restype = None
+    lib.oracle_o1_sphere_uv.argtypes = [_D, _D]
+    lib.oracle_o1_reflectance.restype = C.c_double
+    lib.oracle_o1_reflectance.argtypes = [C.c_double, C.c_double]
+    lib.oracle_o1_refract.restype = None
+    lib.oracle_o1_refract.argtypes = [_D, _D, C.c_double, _D]
+    lib.oracle_o1_reflect.restype = None
+    lib.oracle_o1_reflect.argtypes = [_D, _D, _D]
+    lib.oracle_o1_aabb_hit.restype = C.c_int
+    lib.oracle_o1_aabb_hit.argtypes = [_D, _D, _D, _D, C.c_double, C.c_double]
+    lib.oracle_o1_hit.restype = C.c_int
+    lib.oracle_o1_hit.argtypes = [C.c_void_p, C.c_int32, _D, _D, C.c_double, C.c_double, C.c_double, C.c_uint64, _D]
+    lib.oracle_philox4x32_10.restype = None
+    lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    lib.oracle_splitmix64_next.restype = C.c_uint64
+    lib.oracle_splitmix64_next.argtypes = [C.POINTER(C.c_uint64)]
+    lib.oracle_sample_stream.restype = None
+    lib.oracle_sample_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _D]
+    lib.oracle_rt_math.restype = None
+    lib.oracle_rt_math.argtypes = [C.c_int32, _D, _D, C.c_int64, _D]
+    _lib = lib
+    return lib
+
+
+def _d3(v):
+    return (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+def camera_from(rtx_cam):
+    """RtxCamera (product struct) -> OracleCamera (same layout)."""
+    return OracleCamera.from_buffer_copy(bytes(rtx_cam))
+
+
+def config_from(rtx_cfg, image_height, threads=None, bvh_seed=12345):
+    c = OracleConfig()
+    c.image_width = rtx_cfg.image_width
+    c.image_height = image_height
+    c.samples_per_pixel = rtx_cfg.samples_per_pixel
+    c.max_depth = rtx_cfg.max_depth
+    c.threads = threads if threads is not None else rtx_cfg.threads
+    c.row_chunk_compat = rtx_cfg.row_chunk_compat
+    c.seed = rtx_cfg.seed
+    c.bvh_seed = bvh_seed
+    c.background[0], c.background[1], c.background[2] = rtx_cfg.background[0], rtx_cfg.background[1], rtx_cfg.background[2]
+    return c
+
+
+def o1_render(graph_ptr, world, rtx_cam, rtx_cfg, image_height, threads=None, bvh_seed=12345):
+    """Literal restatement.  Returns (accum[h,w,3] f64, rgb8[h,w,3] u8), row 0 = bottom row."""
+    lib = load()
+    cam = camera_from(rtx_cam)
+    cfg = config_from(rtx_cfg, image_height, threads, bvh_seed)
+    h, w = image_height, rtx_cfg.image_width
+    accum = np.zeros((h, w, 3), dtype=np.float64)
+    rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+    rc = lib.oracle_o1_render(graph_ptr, world, C.byref(cam), C.byref(cfg), accum.ctypes.data_as(_D),
+                              rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != 0:
+        raise RuntimeError("oracle_o1_render failed (%d)" % rc)
+    return accum, rgb8
+
+
+def o2_render(flat_arrays_ptr, rtx_cam, rtx_cfg, image_height, shard=(0, 1, 1), threads=None, counters=False):
+    """Flat-array loop through the product's core headers on the CPU."""
+    lib = load()
+    cam = camera_from(rtx_cam)
+    cfg = config_from(rtx_cfg, image_height, threads)
+    w = rtx_cfg.image_width
+    rows = [j for j in range(image_height) if (j // shard[2]) % shard[1] == shard[0]]
+    accum = np.zeros((len(rows), w, 3), dtype=np.float64)
+    rgb8 = np.zeros((len(rows), w, 3), dtype=np.uint8)
+    cnt = OracleCounters() if counters else None
+    rc = lib.oracle_o2_render(flat_arrays_ptr, C.byref(cam), C.byref(cfg), shard[0], shard[1], shard[2],
+                              accum.ctypes.data_as(_D), rgb8.ctypes.data_as(C.POINTER(C.c_uint8)),
+                              C.byref(cnt) if cnt is not None else None)
+    if rc != 0:
+        raise RuntimeError("oracle_o2_render failed (%d)" % rc)
+    if counters:
+        return accum, rgb8, {n: getattr(cnt, n) for n, _ in OracleCounters._fields_}
+    return accum, rgb8
+
+
+def o2_sample(flat_arrays_ptr, rtx_cam, rtx_cfg, image_height, i, j, s):
+    lib = load()
+    cam = camera_from(rtx_cam)
+    cfg = config_from(rtx_cfg, image_height)
+    out = (C.c_double * 3)()
+    lib.oracle_o2_sample(flat_arrays_ptr, C.byref(cam), C.byref(cfg), i, j, s, out)
+    return np.array(out[:])
+
+
+def rt_math(fn, x, y=None):
+    lib = load()
+    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6}
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
+    out = np.empty_like(x)
+    lib.oracle_rt_math(names[fn], x.ctypes.data_as(_D), y.ctypes.data_as(_D), x.size, out.ctypes.data_as(_D))
+    return out

@@ -1,0 +1,103 @@
+"""Build the HIP shared library (and, for tests, the CPU oracle) in-tree.
+
+    python ray-tracing-series-rust_amd/build.py            # product: lib/librtx_hip.so
+    python ray-tracing-series-rust_amd/build.py --oracle   # + oracle/_build/liboracle.so
+
+hipcc cross-compiles gfx950 code objects without a GPU.  `-ffp-contract=off` is part of the
+parity contract (the reference is Rust: no FMA contraction), not a tuning knob.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "librtx_hip.so")
+APP_PATH = os.path.join(LIB_DIR, "rtx_render")
+ORACLE_DIR = os.path.join(REPO_DIR, "oracle")
+ORACLE_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+HIP_SOURCES = [
+    "csrc/hip/render.hip",
+    "csrc/hip/abi.cpp",
+    "csrc/host/scene_graph.cpp",
+    "csrc/host/flatten.cpp",
+    "csrc/host/bvh_build.cpp",
+    "csrc/host/scenes.cpp",
+]
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def _newest(paths):
+    t = 0.0
+    for p in paths:
+        for root, _, files in os.walk(p) if os.path.isdir(p) else [(os.path.dirname(p), [], [os.path.basename(p)])]:
+            for f in files:
+                fp = os.path.join(root, f)
+                if os.path.exists(fp):
+                    t = max(t, os.path.getmtime(fp))
+    return t
+
+
+def needs_build(target, deps):
+    return (not os.path.exists(target)) or os.path.getmtime(target) < _newest(deps)
+
+
+def build_library(force=False, verbose=True):
+    deps = [os.path.join(PKG_DIR, "csrc"), os.path.join(REPO_DIR, "include")]
+    if not force and not needs_build(LIB_PATH, deps):
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + HIP_FLAGS + ["-shared"] + [os.path.join(PKG_DIR, s) for s in HIP_SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=PKG_DIR)
+    return LIB_PATH
+
+
+def build_app(force=False, verbose=True):
+    """apps/rtx_render: the stand-in for the reference's src/main.rs, linked against the library."""
+    src = os.path.join(PKG_DIR, "apps", "rtx_render.cpp")
+    if not os.path.exists(src):
+        return None
+    if not force and not needs_build(APP_PATH, [src, LIB_PATH]):
+        return APP_PATH
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", src, "-I", os.path.join(REPO_DIR, "include"),
+           "-L", LIB_DIR, "-lrtx_hip", "-Wl,-rpath,$ORIGIN", "-o", APP_PATH]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=PKG_DIR)
+    return APP_PATH
+
+
+def build_oracle(force=False, verbose=True):
+    """Test infrastructure only (oracle/): never loaded by the product."""
+    deps = [ORACLE_DIR + "/o1_literal.cpp", ORACLE_DIR + "/o2_flat.cpp", ORACLE_DIR + "/oracle_abi.h",
+            os.path.join(PKG_DIR, "csrc", "core"), os.path.join(PKG_DIR, "csrc", "host")]
+    if not force and not needs_build(ORACLE_PATH, deps):
+        return ORACLE_PATH
+    cmd = ["make", "-C", ORACLE_DIR] + (["-B"] if force else [])
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return ORACLE_PATH
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    build_library(force=force)
+    build_app(force=force)
+    if "--oracle" in sys.argv:
+        build_oracle(force=force)

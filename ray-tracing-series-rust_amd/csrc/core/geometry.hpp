@@ -1,0 +1,445 @@
+// Ray/primitive intersection, AABB slab test, BVH traversal and the ordered
+// top-level object table -- the L1 half of the hot path.
+//
+// Reference: /root/reference/src/hit.rs (Hittable impls), aabb.rs:23-61,
+// bvh.rs:97-112.  Every primitive test performs the reference's arithmetic in
+// the reference's order; what is re-designed is the control structure around it:
+//   * intersection is split into "find t" (candidate distance) and "finalize"
+//     (hit point, normal, face, uv), so a traversal only carries (t, primitive)
+//     and builds ONE HitRecord per ray instead of one per accepted candidate;
+//   * the recursive, pointer-chasing BvhNode::hit becomes an iterative walk over
+//     a flat node array with an explicit index stack (LDS on the device);
+//   * HittableList / RectPrism become ordered groups, Translate/RotateY become
+//     op lists on an entry, ConstantMedium becomes an entry kind.
+// Closest-hit results are independent of the traversal order; exact ties inside
+// one BVH are resolved as "higher position in the list handed to
+// BvhNode::from_list wins", the order-independent form of the reference's
+// "later object / right child wins" (hit.rs:676-680, bvh.rs:105).
+#pragma once
+#include "flat_types.hpp"
+#include "rng.hpp"
+#include "rt_math.hpp"
+
+namespace rt {
+
+// hit.rs:10-18
+struct HitRecord {
+  Point3 p;
+  Vec3 normal;
+  double t, u, v;
+  bool front_face;
+  int32_t mat;
+};
+
+// hit.rs:69-79
+RT_HD void create_normal_face(const Ray& r, Vec3 outward_normal, Vec3* normal, bool* front_face) {
+  bool ff = dot(r.direction, outward_normal) < 0.0;
+  *normal = ff ? outward_normal : -outward_normal;
+  *front_face = ff;
+}
+
+// hit.rs:195-200
+RT_HD void get_sphere_uv(Point3 p, double* u, double* v) {
+  double theta = rt_acos(-p.y);
+  double phi = rt_atan2(-p.z, p.x) + RT_PI;
+  *u = phi / (2.0 * RT_PI);
+  *v = theta / RT_PI;
+}
+
+RT_HD Vec3 load_v3(const double* p) { return v3(p[0], p[1], p[2]); }
+
+// hit.rs:275-278
+RT_HD Point3 moving_sphere_center(const FlatMovingSphere& s, double time) {
+  Point3 c0 = load_v3(s.c0), c1 = load_v3(s.c1);
+  return c0 + ((time - s.time0) / (s.time1 - s.time0)) * (c1 - c0);
+}
+
+// Shared by Sphere::hit (hit.rs:204-222) and MovingSphere::hit (hit.rs:282-300).
+RT_HD bool sphere_root(Point3 center, double radius, const Ray& r, double t_min, double t_max,
+                       double* t_out) {
+  Vec3 oc = r.origin - center;
+  double a = length_squared(r.direction);
+  double half_b = dot(oc, r.direction);
+  double c = length_squared(oc) - radius * radius;
+  double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return false;
+  double sqrtd = rt_sqrt(discriminant);
+  double root = (-half_b - sqrtd) / a;
+  if (root < t_min || t_max < root) {
+    root = (-half_b + sqrtd) / a;
+    if (root < t_min || t_max < root) return false;
+  }
+  *t_out = root;
+  return true;
+}
+
+// hit.rs:111-149: plane hit, range test, three inside-edge tests.
+RT_HD bool triangle_t(const FlatTriangle& tr, const Ray& r, double t_min, double t_max,
+                      double* t_out) {
+  Vec3 n = load_v3(tr.normal), v0 = load_v3(tr.v0), v1 = load_v3(tr.v1), v2 = load_v3(tr.v2);
+  double n_dot_d = dot(n, r.direction);
+  if (rt_fabs(n_dot_d) < 0.0001) return false;
+  double d = -dot(n, v0);
+  double t = -(dot(n, r.origin) + d) / n_dot_d;
+  if (t < t_min || t > t_max) return false;
+  Point3 p = ray_at(r, t);
+  Vec3 c = cross(v1 - v0, p - v0);
+  if (dot(n, c) < 0.0) return false;
+  c = cross(v2 - v1, p - v1);
+  if (dot(n, c) < 0.0) return false;
+  c = cross(v0 - v2, p - v2);
+  if (dot(n, c) < 0.0) return false;
+  *t_out = t;
+  return true;
+}
+
+// hit.rs:476-485 (Xy), 541-550 (Xz), 606-615 (Yz).
+RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, double* t_out) {
+  double ok, dk, oa, da, ob, db;
+  if (q.axis == RECT_XY) {
+    ok = r.origin.z; dk = r.direction.z; oa = r.origin.x; da = r.direction.x; ob = r.origin.y; db = r.direction.y;
+  } else if (q.axis == RECT_XZ) {
+    ok = r.origin.y; dk = r.direction.y; oa = r.origin.x; da = r.direction.x; ob = r.origin.z; db = r.direction.z;
+  } else {
+    ok = r.origin.x; dk = r.direction.x; oa = r.origin.y; da = r.direction.y; ob = r.origin.z; db = r.direction.z;
+  }
+  double t = (q.k - ok) / dk;
+  if (t < t_min || t > t_max) return false;
+  double x = oa + t * da;
+  double y = ob + t * db;
+  if (x < q.a0 || x > q.a1 || y < q.b0 || y > q.b1) return false;
+  *t_out = t;
+  return true;
+}
+
+template <uint32_t F, bool COUNT>
+RT_HD bool prim_t(const SceneView& sv, PrimRef ref, const Ray& r, double t_min, double t_max,
+                  double* t_out, TraceCounters* cnt) {
+  uint32_t idx = primref_index(ref);
+  uint32_t type = primref_type(ref);
+  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE)))) {
+    if (COUNT) cnt->sphere_tests++;
+    const FlatSphere& s = sv.spheres[idx];
+    return sphere_root(v3(s.cx, s.cy, s.cz), s.radius, r, t_min, t_max, t_out);
+  }
+  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE)))) {
+    if (COUNT) cnt->moving_sphere_tests++;
+    const FlatMovingSphere& s = sv.moving_spheres[idx];
+    return sphere_root(moving_sphere_center(s, r.time), s.radius, r, t_min, t_max, t_out);
+  }
+  if ((F & F_RECT) && (type == PRIM_RECT || !(F & F_TRIANGLE))) {
+    if (COUNT) cnt->rect_tests++;
+    return rect_t(sv.rects[idx], r, t_min, t_max, t_out);
+  }
+  if (F & F_TRIANGLE) {
+    if (COUNT) cnt->triangle_tests++;
+    return triangle_t(sv.triangles[idx], r, t_min, t_max, t_out);
+  }
+  return false;
+}
+
+// Build the HitRecord of the winning primitive (the tail of each Hittable::hit).
+template <uint32_t F>
+RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double t, HitRecord* rec) {
+  uint32_t idx = primref_index(ref);
+  uint32_t type = primref_type(ref);
+  rec->t = t;
+  rec->p = ray_at(r, t);
+  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE)))) {
+    // hit.rs:222-236
+    const FlatSphere& s = sv.spheres[idx];
+    Vec3 outward = (rec->p - v3(s.cx, s.cy, s.cz)) / s.radius;
+    create_normal_face(r, outward, &rec->normal, &rec->front_face);
+    rec->mat = s.mat;
+    rec->u = 0.0; rec->v = 0.0;  // only read by Image textures
+    if (F & F_IMAGE) {
+      if (sv.materials[s.mat].needs_uv) get_sphere_uv(outward, &rec->u, &rec->v);
+    }
+    return;
+  }
+  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE)))) {
+    // hit.rs:301-314 (u = v = 0)
+    const FlatMovingSphere& s = sv.moving_spheres[idx];
+    Vec3 outward = (rec->p - moving_sphere_center(s, r.time)) / s.radius;
+    create_normal_face(r, outward, &rec->normal, &rec->front_face);
+    rec->mat = s.mat;
+    rec->u = 0.0; rec->v = 0.0;
+    return;
+  }
+  if ((F & F_RECT) && (type == PRIM_RECT || !(F & F_TRIANGLE))) {
+    // hit.rs:486-500, 551-565, 616-630
+    const FlatRect& q = sv.rects[idx];
+    double oa, da, ob, db;
+    Vec3 outward;
+    if (q.axis == RECT_XY) { oa = r.origin.x; da = r.direction.x; ob = r.origin.y; db = r.direction.y; outward = v3(0, 0, 1); }
+    else if (q.axis == RECT_XZ) { oa = r.origin.x; da = r.direction.x; ob = r.origin.z; db = r.direction.z; outward = v3(0, 1, 0); }
+    else { oa = r.origin.y; da = r.direction.y; ob = r.origin.z; db = r.direction.z; outward = v3(1, 0, 0); }
+    rec->u = 0.0; rec->v = 0.0;
+    if (F & F_IMAGE) {
+      if (sv.materials[q.mat].needs_uv) {
+        double x = oa + t * da, y = ob + t * db;
+        rec->u = (x - q.a0) / (q.a1 - q.a0);
+        rec->v = (y - q.b0) / (q.b1 - q.b0);
+      }
+    }
+    create_normal_face(r, outward, &rec->normal, &rec->front_face);
+    rec->mat = q.mat;
+    return;
+  }
+  if (F & F_TRIANGLE) {
+    // hit.rs:151-161 (u = v = 1)
+    const FlatTriangle& tr = sv.triangles[idx];
+    create_normal_face(r, load_v3(tr.normal), &rec->normal, &rec->front_face);
+    rec->mat = tr.mat;
+    rec->u = 1.0; rec->v = 1.0;
+  }
+}
+
+// aabb.rs:23-61.  inv_d is the reference's per-axis 1.0/direction (hoisted out of
+// the node loop: same value every time).  The reference returns false at the
+// first axis where t_max <= t_min; since t_min only grows and t_max only shrinks
+// that is equivalent to testing once after the third axis.
+RT_HD bool aabb_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min,
+                    double t_max) {
+  {
+    double t0 = (bmin[0] - o.x) * inv_d.x, t1 = (bmax[0] - o.x) * inv_d.x;
+    if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  {
+    double t0 = (bmin[1] - o.y) * inv_d.y, t1 = (bmax[1] - o.y) * inv_d.y;
+    if (inv_d.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  {
+    double t0 = (bmin[2] - o.z) * inv_d.z, t1 = (bmax[2] - o.z) * inv_d.z;
+    if (inv_d.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  return !(t_max <= t_min);
+}
+
+// A traversal's running answer.
+struct Closest {
+  double t;
+  PrimRef ref;
+  uint32_t order;  // slot in the owning list (tie break)
+  bool hit;
+};
+
+// Offer one primitive to the running closest hit.  Range rejection is the
+// reference's (strict on both ends, so t == closest is accepted); `order`
+// makes the tie outcome independent of the visiting order.
+template <uint32_t F, bool COUNT>
+RT_HD void offer_prim(const SceneView& sv, PrimRef ref, uint32_t order, const Ray& r, double t_min,
+                      Closest* best, TraceCounters* cnt) {
+  double t;
+  if (!prim_t<F, COUNT>(sv, ref, r, t_min, best->t, &t, cnt)) return;
+  if (best->hit && t == best->t && order < best->order) return;
+  best->t = t;
+  best->ref = ref;
+  best->order = order;
+  best->hit = true;
+}
+
+// Iterative closest-hit walk of one flattened BVH.  STACK provides
+// reset() / push(int32_t) / pop() / empty(); the device instantiates it over LDS.
+// Children are visited near-first along the node's split axis (pure ordering: the
+// closest hit does not depend on it).
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD void bvh_closest(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r,
+                       double t_min, Closest* best, STACK& stack, TraceCounters* cnt) {
+  Vec3 inv_d = v3(1.0 / r.direction.x, 1.0 / r.direction.y, 1.0 / r.direction.z);
+  stack.reset();
+  int32_t node = root;
+  for (;;) {
+    const FlatNode& n = sv.nodes[node];
+    if (COUNT) cnt->box_tests += 2;
+    int32_t axis = n.pad[0];
+    double dir_a = axis == 0 ? r.direction.x : (axis == 1 ? r.direction.y : r.direction.z);
+    int first = dir_a < 0.0 ? 1 : 0;
+    bool hf = aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best->t);
+    int32_t cf = n.child[first];
+    int32_t next = -1;
+    bool have_next = false;
+    if (hf) {
+      if (node_child_is_leaf(cf)) {
+        uint32_t f = leaf_first(cf), k = leaf_count(cf);
+        for (uint32_t i = 0; i < k; ++i)
+          offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
+      } else {
+        next = cf; have_next = true;
+      }
+    }
+    // the far box is tested after the near leaf may have shrunk best->t
+    bool hs = aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best->t);
+    int32_t cs = n.child[1 - first];
+    if (hs) {
+      if (node_child_is_leaf(cs)) {
+        uint32_t f = leaf_first(cs), k = leaf_count(cs);
+        for (uint32_t i = 0; i < k; ++i)
+          offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
+      } else if (have_next) {
+        stack.push(cs);
+      } else {
+        next = cs; have_next = true;
+      }
+    }
+    if (have_next) { node = next; continue; }
+    if (stack.empty()) break;
+    node = stack.pop();
+  }
+}
+
+// PRIM / GROUP / BVH entries: find the closest candidate in [t_min, t_max].
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, double t_min,
+                        double t_max, Closest* best, STACK& stack, TraceCounters* cnt) {
+  best->t = t_max;
+  best->hit = false;
+  best->ref = 0;
+  best->order = 0;
+  if ((F & F_BVH) && (e.kind == ENTRY_BVH || !(F & (F_PRIM_ENTRY | F_GROUP)))) {
+    bvh_closest<F, COUNT>(sv, e.a, (uint32_t)e.b, r, t_min, best, stack, cnt);
+    return;
+  }
+  if ((F & F_PRIM_ENTRY) && (e.kind == ENTRY_PRIM || !(F & F_GROUP))) {
+    double t;
+    if (prim_t<F, COUNT>(sv, (PrimRef)e.a, r, t_min, t_max, &t, cnt)) {
+      best->t = t; best->ref = (PrimRef)e.a; best->hit = true;
+    }
+    return;
+  }
+  if (F & F_GROUP) {
+    // HittableList::hit (hit.rs:660-690): in order, shrinking closest_so_far, later wins ties.
+    for (int32_t i = 0; i < e.b; ++i) {
+      PrimRef ref = sv.refs[e.a + i];
+      double t;
+      if (prim_t<F, COUNT>(sv, ref, r, t_min, best->t, &t, cnt)) {
+        best->t = t; best->ref = ref; best->order = (uint32_t)i; best->hit = true;
+      }
+    }
+  }
+}
+
+// hit.rs:802-807 / 892-904: the ray seen by the child of one transform op.
+RT_HD Ray xform_ray(const FlatXformOp& op, const Ray& r) {
+  if (op.op == XFORM_TRANSLATE) {
+    return make_ray(r.origin - load_v3(op.v), r.direction, r.time);
+  }
+  double sin_t = op.v[0], cos_t = op.v[1];
+  Vec3 o = v3(cos_t * r.origin.x - sin_t * r.origin.z, r.origin.y,
+              sin_t * r.origin.x + cos_t * r.origin.z);
+  Vec3 d = v3(cos_t * r.direction.x - sin_t * r.direction.z, r.direction.y,
+              sin_t * r.direction.x + cos_t * r.direction.z);
+  return make_ray(o, d, r.time);
+}
+
+// hit.rs:808-820 / 909-930: map the child's record back out through one op.
+// `child_ray` is the ray the op handed to its child; both ops re-face-forward
+// the normal against THAT ray (Translate: same direction as the outer ray;
+// RotateY: the rotated ray against the un-rotated normal -- reproduced as is).
+RT_HD void xform_record(const FlatXformOp& op, const Ray& child_ray, HitRecord* rec) {
+  if (op.op == XFORM_TRANSLATE) {
+    create_normal_face(child_ray, rec->normal, &rec->normal, &rec->front_face);
+    rec->p = rec->p + load_v3(op.v);
+    return;
+  }
+  double sin_t = op.v[0], cos_t = op.v[1];
+  Vec3 p = v3(cos_t * rec->p.x + sin_t * rec->p.z, rec->p.y, -sin_t * rec->p.x + cos_t * rec->p.z);
+  Vec3 n = v3(cos_t * rec->normal.x + sin_t * rec->normal.z, rec->normal.y,
+              -sin_t * rec->normal.x + cos_t * rec->normal.z);
+  rec->p = p;
+  create_normal_face(child_ray, n, &rec->normal, &rec->front_face);
+}
+
+// The world: HittableList::hit over the ordered top-level table (hit.rs:660-690), with
+// Translate / RotateY (hit.rs:802-823, 892-931) and ConstantMedium (hit.rs:955-986) handled
+// around ONE geometry query site so the traversal code exists once in the kernel.
+//
+// A ConstantMedium asks its boundary twice (rec1 over (-inf, inf), rec2 from rec1.t + 0.0001),
+// then draws one uniform from the path's stream -- inside the intersection, exactly where
+// the reference draws it (hit.rs:969).
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_max, HitRecord* rec,
+                     Rng& rng, STACK& stack, TraceCounters* cnt) {
+  if (COUNT) cnt->rays++;
+  bool hit_anything = false;
+  double closest_so_far = t_max;
+  for (int32_t i = 0; i < sv.n_top_level; ++i) {
+    const FlatEntry* e = &sv.entries[sv.top_level[i]];
+    const bool is_medium = (F & F_MEDIUM) && e->kind == ENTRY_MEDIUM;
+    const FlatEntry* solid = is_medium ? &sv.entries[e->a] : e;
+    // rays through the (up to two) transform ops, outermost first
+    const bool is_xform = (F & F_XFORM) && solid->kind == ENTRY_XFORM;
+    Ray r1 = r, r2 = r;
+    const FlatEntry* geom = solid;
+    int nops = 0;
+    if (is_xform) {
+      nops = solid->b;
+      geom = &sv.entries[solid->a];
+      r1 = xform_ray(solid->ops[0], r);
+      r2 = (nops > 1) ? xform_ray(solid->ops[1], r1) : r1;
+    }
+    const Ray& rq = is_xform ? r2 : r;
+
+    Closest best;
+    double q_min = is_medium ? -RT_INFINITY : t_min;
+    double q_max = is_medium ? RT_INFINITY : closest_so_far;
+    double rec1_t = 0.0;
+    bool ok = true;
+    const int n_query = is_medium ? 2 : 1;
+    for (int q = 0; q < n_query; ++q) {
+      geom_closest<F, COUNT>(sv, *geom, rq, q_min, q_max, &best, stack, cnt);
+      if (!best.hit) { ok = false; break; }
+      if (q == 0) { rec1_t = best.t; q_min = rec1_t + 0.0001; }
+    }
+    if (!ok) continue;
+
+    HitRecord tmp;
+    if (is_medium) {
+      double rec2_t = best.t;
+      double t1 = rt_fmax(rec1_t, t_min);
+      double t2 = rt_fmin(rec2_t, closest_so_far);
+      if (t1 >= t2) continue;
+      if (t1 < 0.0) t1 = 0.0;
+      double ray_length = length(r.direction);
+      double distance_inside_boundary = (t2 - t1) * ray_length;
+      double hit_distance = e->f[0] * rt_log(rng_f64(rng));
+      if (hit_distance > distance_inside_boundary) continue;
+      double t = t1 + hit_distance / ray_length;
+      tmp.t = t;
+      tmp.p = ray_at(r, t);
+      tmp.normal = v3(0, 0, 0);
+      tmp.front_face = true;
+      tmp.u = 0.0; tmp.v = 0.0;
+      tmp.mat = e->b;
+    } else {
+      prim_finalize<F>(sv, best.ref, rq, best.t, &tmp);
+      if (is_xform) {
+        if (nops > 1) xform_record(solid->ops[1], r2, &tmp);
+        xform_record(solid->ops[0], r1, &tmp);
+      }
+    }
+    hit_anything = true;
+    closest_so_far = tmp.t;
+    *rec = tmp;
+  }
+  return hit_anything;
+}
+
+// Host-side stack (the device uses an LDS-backed one, see hip/trace_kernels.hip).
+template <int N>
+struct LocalStack {
+  int32_t data[N];
+  int n;
+  RT_HD void reset() { n = 0; }
+  RT_HD void push(int32_t v) { data[n++] = v; }
+  RT_HD int32_t pop() { return data[--n]; }
+  RT_HD bool empty() const { return n == 0; }
+};
+
+}  // namespace rt

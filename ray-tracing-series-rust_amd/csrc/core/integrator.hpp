@@ -1,0 +1,73 @@
+// One camera path = one (pixel, sample) of render_scene's inner loop.
+//
+// Reference: /root/reference/src/world.rs:1211-1215 (jitter, primary ray,
+// accumulate) and world.rs:52-93 (ray_color's iterative bounce loop).  The path
+// is exposed as begin/step so the device can interleave many paths per lane
+// (regeneration) while the CPU checker simply loops step() to completion; both
+// execute the same arithmetic in the same order.
+#pragma once
+#include "shading.hpp"
+
+namespace rt {
+
+struct PathState {
+  Ray ray;
+  Color product;  // world.rs:59
+  Color output;   // world.rs:60
+  int32_t depth;  // world.rs:56 (counts down)
+  Rng rng;
+};
+
+// world.rs:1212-1214: u = (i + rand)/(w-1), v = (j + rand)/(h-1), cam.get_ray(u, v).
+// (i, j) = (column, row) with j = 0 the BOTTOM row, as the reference's Screen stores it.
+RT_HD void path_begin(const RenderParams& rp, uint32_t i, uint32_t j, uint32_t sample, PathState* ps) {
+  uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.image_width + (uint64_t)i;
+  ps->rng = rng_for_sample(rp.seed, pixel_index, sample);
+  double ru = rng_f64(ps->rng);
+  double u = ((double)i + ru) / (double)(rp.image_width - 1);
+  double rv = rng_f64(ps->rng);
+  double v = ((double)j + rv) / (double)(rp.image_height - 1);
+  ps->ray = camera_get_ray(rp.cam, u, v, ps->rng);
+  ps->product = v3(1, 1, 1);
+  ps->output = v3(0, 0, 0);
+  ps->depth = rp.max_depth;
+}
+
+// One iteration of ray_color's loop.  Returns true when the path has ended and
+// ps->output holds the sample's radiance.
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps, STACK& stack,
+                     TraceCounters* cnt) {
+  ps->depth -= 1;                  // world.rs:64
+  if (ps->depth < 0) return true;  // world.rs:65-67: no background term on exhaustion
+  HitRecord rec;
+  if (!world_hit<F, COUNT>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt)) {
+    ps->output += ps->product * rp.background;  // world.rs:86-89
+    return true;
+  }
+  const FlatMaterial& m = sv.materials[rec.mat];
+  Ray scattered;
+  Color attenuation;
+  // world.rs:69-84: scatter first (it draws from the stream), then emitted.
+  bool did_scatter = material_scatter<F, COUNT>(sv, m, ps->ray, rec, ps->rng, &scattered, &attenuation, cnt);
+  Color emitted = material_emitted<F, COUNT>(sv, m, rec, cnt);
+  ps->output += emitted * ps->product;
+  if (!did_scatter) return true;
+  ps->product *= attenuation;
+  ps->ray = scattered;
+  return false;
+}
+
+// Whole sample on one thread (CPU checker; also the device's simplest kernel).
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD Color trace_sample(const SceneView& sv, const RenderParams& rp, uint32_t i, uint32_t j,
+                         uint32_t sample, STACK& stack, TraceCounters* cnt) {
+  PathState ps;
+  path_begin(rp, i, j, sample, &ps);
+  if (COUNT) cnt->samples++;
+  while (!path_step<F, COUNT>(sv, rp, &ps, stack, cnt)) {
+  }
+  return ps.output;
+}
+
+}  // namespace rt

@@ -1,0 +1,100 @@
+// Counter-based per-(pixel, sample) random streams.
+//
+// The reference draws every random number from rand::thread_rng() (OS-seeded
+// ChaCha12; call sites: /root/reference/src/world.rs:1212-1213, camera.rs:61,69,
+// vec3.rs:273-322, hit.rs:969,1007,1040,1074,1118), so it has no reproducible
+// stream to match.  This build replaces it with a stream that is a pure function
+// of (render seed, global pixel index, sample index):
+//
+//   stream state  = Philox4x32-10( counter = {pixel_lo, pixel_hi, sample, 0},
+//                                  key     = {seed_lo, seed_hi} )     (128 bits)
+//   k-th draw     = k-th output of xoroshiro128++ started from that state
+//   uniform f64   = (u64 >> 11) * 2^-53   in [0,1)   (53 high bits, as rand 0.8's
+//                                                      Standard f64 distribution)
+//   range(a,b)    = a + (b - a) * uniform
+//
+// Philox (Salmon et al., SC'11) gives statistically independent streams for
+// every (pixel, sample) at one evaluation per path; xoroshiro128++ (Blackman &
+// Vigna) is multiply-free, which matters on CDNA where 32-bit integer multiplies
+// are quarter rate and a path draws ~20-30 doubles.  Scheduling (which lane,
+// wave, GPU or CPU thread runs a sample) cannot change any draw.
+#pragma once
+#include "rt_config.hpp"
+
+namespace rt {
+
+RT_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * (uint64_t)c[0];
+    uint64_t p1 = (uint64_t)M1 * (uint64_t)c[2];
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c[1] ^ k0;
+    uint32_t n1 = lo1;
+    uint32_t n2 = hi0 ^ c[3] ^ k1;
+    uint32_t n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+struct Rng {
+  uint64_t s0, s1;
+};
+
+RT_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+RT_HD Rng rng_for_sample(uint64_t seed, uint64_t pixel_index, uint32_t sample) {
+  uint32_t c[4];
+  c[0] = (uint32_t)pixel_index;
+  c[1] = (uint32_t)(pixel_index >> 32);
+  c[2] = sample;
+  c[3] = 0u;
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  Rng r;
+  r.s0 = (uint64_t)c[0] | ((uint64_t)c[1] << 32);
+  r.s1 = (uint64_t)c[2] | ((uint64_t)c[3] << 32);
+  if ((r.s0 | r.s1) == 0) r.s0 = 0x9E3779B97F4A7C15ull;  // xoroshiro must not start at 0
+  return r;
+}
+
+// xoroshiro128++ (a=49, b=21, c=28; output rotl(s0+s1,17)+s0).
+RT_HD uint64_t rng_next_u64(Rng& r) {
+  uint64_t s0 = r.s0, s1 = r.s1;
+  uint64_t result = rotl64(s0 + s1, 17) + s0;
+  s1 ^= s0;
+  r.s0 = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
+  r.s1 = rotl64(s1, 28);
+  return result;
+}
+
+RT_HD double u64_to_unit_f64(uint64_t x) {
+  // (x >> 11) has at most 53 significant bits: the conversion and the scaling
+  // by a power of two are both exact.
+  return (double)(x >> 11) * 0x1.0p-53;
+}
+
+// rng.gen::<f64>()
+RT_HD double rng_f64(Rng& r) { return u64_to_unit_f64(rng_next_u64(r)); }
+// rng.gen_range(lo..hi) for f64
+RT_HD double rng_range(Rng& r, double lo, double hi) { return lo + (hi - lo) * rng_f64(r); }
+
+// SplitMix64: host-side generator for scene construction (random sphere
+// placement, box heights, Perlin tables, the oracle's reference-rule BVH axis).
+struct HostRng {
+  uint64_t state;
+};
+RT_HD uint64_t host_rng_next_u64(HostRng& h) {
+  uint64_t z = (h.state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+RT_HD double host_rng_f64(HostRng& h) { return u64_to_unit_f64(host_rng_next_u64(h)); }
+RT_HD double host_rng_range(HostRng& h, double lo, double hi) { return lo + (hi - lo) * host_rng_f64(h); }
+// gen_range(lo..hi) for integers, lo < hi.
+RT_HD uint64_t host_rng_below(HostRng& h, uint64_t n) { return host_rng_next_u64(h) % n; }
+
+}  // namespace rt

@@ -1,0 +1,64 @@
+// Shared host/device arithmetic core -- build configuration.
+//
+// Every header under core/ is compiled twice: by hipcc for gfx950 (the product's
+// kernels) and by g++ for the host (scene construction in the product, and the
+// CPU checkers under oracle/).  Both compilations MUST use -ffp-contract=off:
+// the reference is Rust, which never contracts a*b+c into an FMA, and the parity
+// gate between the HIP path and the CPU oracle is bit-exact f64.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#define RT_HD_NOINLINE __host__ __device__
+#else
+#define RT_HD inline
+#define RT_HD_NOINLINE
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_DEVICE_CODE 1
+#else
+#define RT_DEVICE_CODE 0
+#endif
+
+namespace rt {
+
+typedef double real;
+
+// Bit casts (memcpy-free so they stay in registers on the device).
+RT_HD uint64_t f64_bits(double x) {
+  union { double d; uint64_t u; } c; c.d = x; return c.u;
+}
+RT_HD double bits_f64(uint64_t u) {
+  union { double d; uint64_t u; } c; c.u = u; return c.d;
+}
+RT_HD uint32_t f64_hi(double x) { return (uint32_t)(f64_bits(x) >> 32); }
+RT_HD uint32_t f64_lo(double x) { return (uint32_t)(f64_bits(x)); }
+RT_HD double f64_from_words(uint32_t hi, uint32_t lo) {
+  return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+#define RT_INFINITY (__builtin_huge_val())
+
+// IEEE-exact primitives used by the core.  sqrt/fabs/floor are correctly
+// rounded (or exact) on both x86-64 and gfx950, so they are safe to share.
+RT_HD double rt_sqrt(double x) { return __builtin_sqrt(x); }
+RT_HD double rt_fabs(double x) { return __builtin_fabs(x); }
+RT_HD double rt_floor(double x) { return __builtin_floor(x); }
+// Rust f64::min / f64::max: a NaN operand is ignored (== C fmin/fmax).
+RT_HD double rt_fmin(double a, double b) { return __builtin_fmin(a, b); }
+RT_HD double rt_fmax(double a, double b) { return __builtin_fmax(a, b); }
+RT_HD bool rt_isnan(double x) { return x != x; }
+
+// Rust `x as i32` for f64: saturating, NaN -> 0 (vec3.rs:103-105, perlin.rs:33-35,
+// texture.rs:107-108).
+RT_HD int32_t rt_f64_as_i32(double x) {
+  if (rt_isnan(x)) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (int32_t)(-2147483647 - 1);
+  return (int32_t)x;
+}
+
+}  // namespace rt

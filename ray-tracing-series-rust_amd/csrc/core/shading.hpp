@@ -1,0 +1,186 @@
+// Samplers, textures, Perlin noise and material scatter -- the L2 half of the hot path.
+//
+// Reference: /root/reference/src/vec3.rs:273-322 (samplers), texture.rs (textures),
+// perlin.rs:28-106 (noise), hit.rs:992-1152 (materials).  Draw order from the
+// path's stream is the reference's draw order.
+#pragma once
+#include "geometry.hpp"
+
+namespace rt {
+
+// vec3.rs:273-276
+RT_HD Vec3 random_vec3(Rng& g) {
+  double x = rng_f64(g), y = rng_f64(g), z = rng_f64(g);
+  return v3(x, y, z);
+}
+// vec3.rs:278-285
+RT_HD Vec3 random_range_vec3(Rng& g, double mn, double mx) {
+  double x = rng_range(g, mn, mx), y = rng_range(g, mn, mx), z = rng_range(g, mn, mx);
+  return v3(x, y, z);
+}
+// vec3.rs:287-295
+RT_HD Vec3 random_in_unit_sphere(Rng& g) {
+  for (;;) {
+    Vec3 p = random_range_vec3(g, -1.0, 1.0);
+    if (length_squared(p) < 1.0) return p;
+  }
+}
+// vec3.rs:297-299
+RT_HD Vec3 random_unit_vector(Rng& g) { return unit(random_in_unit_sphere(g)); }
+// vec3.rs:310-322
+RT_HD Vec3 random_in_unit_disk(Rng& g) {
+  for (;;) {
+    double x = rng_range(g, -1.0, 1.0), y = rng_range(g, -1.0, 1.0);
+    Vec3 p = v3(x, y, 0.0);
+    if (length_squared(p) < 1.0) return p;
+  }
+}
+
+// camera.rs:59-71.  The lens sample and the shutter time are drawn even when
+// aperture is 0 / the shutter interval is a single instant's worth.
+RT_HD Ray camera_get_ray(const FlatCamera& c, double s, double t, Rng& g) {
+  Vec3 rd = c.lens_radius * random_in_unit_disk(g);
+  Vec3 offset = c.u * rd.x + c.v * rd.y;
+  Point3 origin = c.origin + offset;
+  Vec3 direction = c.lower_left_corner + s * c.horizontal + t * c.vertical - c.origin - offset;
+  double time = rng_range(g, c.time1, c.time2);
+  return make_ray(origin, direction, time);
+}
+
+// perlin.rs:28-52 + 85-106 (gradient fetch fused into the interpolation loop; same values).
+template <bool COUNT>
+RT_HD double perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
+  if (COUNT) cnt->perlin_calls++;
+  double fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
+  double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  uint32_t i = (uint32_t)rt_f64_as_i32(fx), j = (uint32_t)rt_f64_as_i32(fy), k = (uint32_t)rt_f64_as_i32(fz);
+  double uu = u * u * (3.0 - 2.0 * u);
+  double vv = v * v * (3.0 - 2.0 * v);
+  double ww = w * w * (3.0 - 2.0 * w);
+  double accum = 0.0;
+  for (uint32_t di = 0; di < 2; ++di)
+    for (uint32_t dj = 0; dj < 2; ++dj)
+      for (uint32_t dk = 0; dk < 2; ++dk) {
+        int32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
+        Vec3 c = load_v3(pn.ranvec[h]);
+        double i1 = (double)di, j1 = (double)dj, k1 = (double)dk;
+        Vec3 weight_v = v3(u - i1, v - j1, w - k1);
+        accum += (i1 * uu + (1.0 - i1) * (1.0 - uu)) * (j1 * vv + (1.0 - j1) * (1.0 - vv)) *
+                 (k1 * ww + (1.0 - k1) * (1.0 - ww)) * dot(c, weight_v);
+      }
+  return accum;
+}
+
+// perlin.rs:54-66
+template <bool COUNT>
+RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceCounters* cnt) {
+  double accum = 0.0;
+  Point3 temp_p = p;
+  double weight = 1.0;
+  for (int i = 0; i < depth; ++i) {
+    accum += weight * perlin_noise<COUNT>(pn, temp_p, cnt);
+    weight *= 0.5;
+    temp_p = temp_p * 2.0;
+  }
+  return rt_fabs(accum);
+}
+
+// Texture::value for the whole texture tree (texture.rs:27-31, 54-64, 80-88, 102-121).
+// Checker picks a child from p alone, so nested checkers resolve iteratively.
+template <uint32_t F, bool COUNT>
+RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, Point3 p,
+                          TraceCounters* cnt) {
+  if (F & F_CHECKER) {
+    for (int guard = 0; guard < 16; ++guard) {
+      const FlatTexture& t = sv.textures[tex];
+      if (t.kind != TEX_CHECKER) break;
+      double sines = rt_sin(10.0 * p.x) * rt_sin(10.0 * p.y) * rt_sin(10.0 * p.z);
+      tex = (sines < 0.0) ? t.b : t.a;
+    }
+  }
+  const FlatTexture& t = sv.textures[tex];
+  if ((F & F_NOISE) && t.kind == TEX_NOISE) {
+    double s = 1.0 + rt_sin(t.scale * p.z + 10.0 * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
+    return v3(1.0, 1.0, 1.0) * 0.5 * s;
+  }
+  if ((F & F_IMAGE) && t.kind == TEX_IMAGE) {
+    if (COUNT) cnt->texels++;
+    const FlatImage& im = sv.images[t.a];
+    double uc = clamp(u, 0.0, 1.0);
+    double vc = 1.0 - clamp(v, 0.0, 1.0);
+    int32_t i = rt_f64_as_i32(uc * (double)im.width);
+    int32_t j = rt_f64_as_i32(vc * (double)im.height);
+    i = i < im.width - 1 ? i : im.width - 1;
+    j = j < im.height - 1 ? j : im.height - 1;
+    const double color_scale = 1.0 / 255.0;
+    const double* px = sv.texels + 3 * (im.first_texel + (int64_t)j * im.width + i);
+    return v3(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+  }
+  return load_v3(t.color);  // TEX_SOLID
+}
+
+// hit.rs:1095-1099;  f64::powi(x, 5) == x * (x*x) * (x*x) evaluated as ((x^2)^2)*x by
+// LLVM's powi expansion (square-and-multiply from the low bit: r = x; x2 = x*x; x4 = x2*x2; r*x4).
+RT_HD double reflectance(double cosine, double ref_idx) {
+  double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+  r0 = r0 * r0;
+  double b = 1.0 - cosine;
+  double b2 = b * b;
+  double b4 = b2 * b2;
+  return r0 + (1.0 - r0) * (b * b4);
+}
+
+// Material::emitted (hit.rs:1015-1017 default, 1149-1151 DiffuseLight).
+template <uint32_t F, bool COUNT>
+RT_HD Color material_emitted(const SceneView& sv, const FlatMaterial& m, const HitRecord& rec,
+                             TraceCounters* cnt) {
+  if ((F & F_LIGHT) && m.kind == MAT_DIFFUSE_LIGHT)
+    return texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+  return v3(0, 0, 0);
+}
+
+// Material::scatter for all five materials.
+template <uint32_t F, bool COUNT>
+RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ray& r_in,
+                            const HitRecord& rec, Rng& g, Ray* scattered, Color* attenuation,
+                            TraceCounters* cnt) {
+  if (COUNT) cnt->scatters++;
+  if ((F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN) {  // hit.rs:1039-1051
+    Vec3 scatter_direction = rec.normal + random_unit_vector(g);
+    if (near_zero(scatter_direction)) scatter_direction = rec.normal;
+    *scattered = make_ray(rec.p, scatter_direction, r_in.time);
+    *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+    return true;
+  }
+  if ((F & F_METAL) && m.kind == MAT_METAL) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
+    Vec3 reflected = reflect(unit(r_in.direction), rec.normal);
+    Vec3 dir = reflected + m.param * random_in_unit_sphere(g);
+    *scattered = make_ray(rec.p, dir, r_in.time);
+    *attenuation = load_v3(m.albedo);
+    return dot(dir, rec.normal) > 0.0;
+  }
+  if ((F & F_DIELECTRIC) && m.kind == MAT_DIELECTRIC) {  // hit.rs:1103-1126 (uniform drawn only if refraction is possible)
+    double refraction_ratio = rec.front_face ? (1.0 / m.param) : m.param;
+    Vec3 unit_direction = unit(r_in.direction);
+    double cos_theta = rt_fmin(dot(-unit_direction, rec.normal), 1.0);
+    double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
+    bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+    Vec3 direction;
+    if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_f64(g))
+      direction = reflect(unit_direction, rec.normal);
+    else
+      direction = refract(unit_direction, rec.normal, refraction_ratio);
+    *scattered = make_ray(rec.p, direction, r_in.time);
+    *attenuation = v3(1, 1, 1);
+    return true;
+  }
+  if ((F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC) {  // hit.rs:1005-1010
+    Vec3 dir = random_in_unit_sphere(g);
+    *scattered = make_ray(rec.p, dir, r_in.time);
+    *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+    return true;
+  }
+  return false;  // MAT_DIFFUSE_LIGHT, hit.rs:1146-1148
+}
+
+}  // namespace rt

@@ -1,0 +1,525 @@
+// HIP kernels and launcher for the per-pixel x per-sample loop of render_scene
+// (/root/reference/src/world.rs:1207-1226) on gfx950.
+//
+//   k_trace_*        one camera path per (pixel, sample): path_begin + path_step loop
+//                    (core/integrator.hpp), radiance written to the pass's sample buffer
+//   k_reduce_samples per pixel, adds the pass's samples IN SAMPLE ORDER onto the accumulator
+//                    (the reference's `pixel += ray_color(..)` order, world.rs:1215, so sums
+//                    are bit-identical to a sequential CPU loop whatever the scheduling was)
+//   k_tonemap        get_normalized_color (vec3.rs:89-107) -> RGB8
+//
+// No CPU fallback exists in this library: without a GPU every render entry point returns
+// RTX_EHIP.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../../include/rtx_abi.h"
+#include "../core/integrator.hpp"
+#include "../host/flat_scene.hpp"
+#include "abi_internal.hpp"
+
+namespace rtx {
+
+// ------------------------------------------------------------------ device scene
+struct DeviceScene {
+  int device = -1;
+  std::vector<void*> allocations;
+  rt::SceneView view;   // device pointers
+  size_t scene_bytes = 0;
+  int32_t n_nodes = 0;
+  // workspace (grown on demand by render calls)
+  double* samples = nullptr;
+  size_t samples_bytes = 0;
+  double* accum = nullptr;
+  size_t accum_bytes = 0;
+  rt::TraceCounters* counters = nullptr;
+  unsigned int* work_counter = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int n_cu = 256;
+  int blocks_per_cu[3] = {1, 1, 1};  // resident 256-thread blocks per CU for each preset's persistent kernel
+  bool force_simple = false;          // RTX_TRACE_KERNEL=simple
+};
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+      return RTX_EHIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+static rtx_status upload_array(DeviceScene* ds, const std::vector<T>& v, const T** out) {
+  *out = nullptr;
+  if (v.empty()) return RTX_OK;
+  void* p = nullptr;
+  size_t bytes = v.size() * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes));
+  ds->allocations.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+  ds->scene_bytes += bytes;
+  *out = (const T*)p;
+  return RTX_OK;
+}
+
+static void free_device_scene(DeviceScene* ds) {
+  if (!ds) return;
+  for (void* p : ds->allocations) (void)hipFree(p);
+  if (ds->samples) (void)hipFree(ds->samples);
+  if (ds->accum) (void)hipFree(ds->accum);
+  if (ds->counters) (void)hipFree(ds->counters);
+  if (ds->work_counter) (void)hipFree(ds->work_counter);
+  for (int i = 0; i < 2; ++i)
+    if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
+  delete ds;
+}
+
+// ------------------------------------------------------------------ pixel enumeration
+// Local pixel lp of a shard -> image (column i, row j).  Rows of a shard are the rows j with
+// (j / block_rows) % shard_count == shard_index, compacted in ascending j.
+struct ShardMap {
+  int32_t width, block_rows, shard_index, shard_count;
+};
+__device__ __forceinline__ void shard_pixel(const ShardMap& m, uint32_t lp, uint32_t* i, uint32_t* j) {
+  uint32_t lr = lp / (uint32_t)m.width;
+  *i = lp - lr * (uint32_t)m.width;
+  uint32_t k = lr / (uint32_t)m.block_rows;
+  uint32_t within = lr - k * (uint32_t)m.block_rows;
+  *j = (k * (uint32_t)m.shard_count + (uint32_t)m.shard_index) * (uint32_t)m.block_rows + within;
+}
+
+// ------------------------------------------------------------------ LDS traversal stack
+// Slot (level, lane) lives at base[level * TRACE_BLOCK]: lanes of a wave touch consecutive
+// dwords -> conflict-free ds_write_b32 / ds_read_b32.
+#define TRACE_BLOCK 256
+struct LdsStack {
+  int32_t* base;
+  int n;
+  __device__ __forceinline__ void reset() { n = 0; }
+  __device__ __forceinline__ void push(int32_t v) { base[n * TRACE_BLOCK] = v; ++n; }
+  __device__ __forceinline__ int32_t pop() { --n; return base[n * TRACE_BLOCK]; }
+  __device__ __forceinline__ bool empty() const { return n == 0; }
+};
+
+__device__ __forceinline__ void flush_counters(const rt::TraceCounters& c, rt::TraceCounters* g) {
+  atomicAdd(&g->box_tests, c.box_tests);
+  atomicAdd(&g->sphere_tests, c.sphere_tests);
+  atomicAdd(&g->moving_sphere_tests, c.moving_sphere_tests);
+  atomicAdd(&g->rect_tests, c.rect_tests);
+  atomicAdd(&g->triangle_tests, c.triangle_tests);
+  atomicAdd(&g->scatters, c.scatters);
+  atomicAdd(&g->texels, c.texels);
+  atomicAdd(&g->perlin_calls, c.perlin_calls);
+  atomicAdd(&g->rays, c.rays);
+  atomicAdd(&g->samples, c.samples);
+}
+
+// ------------------------------------------------------------------ kernels
+// Feature presets the trace kernels are compiled for (see core/flat_types.hpp Feature).
+constexpr uint32_t P_SPHERES = rt::F_SPHERE | rt::F_MOVING_SPHERE | rt::F_BVH | rt::F_LAMBERTIAN |
+                               rt::F_METAL | rt::F_DIELECTRIC | rt::F_CHECKER;
+constexpr uint32_t P_MESH = rt::F_SPHERE | rt::F_RECT | rt::F_TRIANGLE | rt::F_PRIM_ENTRY | rt::F_GROUP |
+                            rt::F_BVH | rt::F_LAMBERTIAN | rt::F_METAL | rt::F_DIELECTRIC | rt::F_LIGHT;
+constexpr uint32_t P_ALL = rt::F_ALL;
+
+// Straightforward form: grid-stride over the pass's (sample, pixel) index space, one whole
+// path per loop iteration.  g = s_local * npix + lp, so a wave's lanes are 64 consecutive
+// pixels of the same sample: coherent primary rays, coalesced sample-buffer stores.
+// Kept as the A/B partner of k_trace_persistent (RTX_TRACE_KERNEL=simple) and as the
+// instrumented (COUNT) build.
+template <uint32_t F, bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_simple(rt::SceneView sv, rt::RenderParams rp,
+                                                               ShardMap sm, uint32_t s_begin,
+                                                               uint32_t total, uint32_t npix,
+                                                               double* __restrict__ samples,
+                                                               rt::TraceCounters* counters) {
+  extern __shared__ int32_t lds_stack[];
+  LdsStack stack;
+  stack.base = lds_stack + threadIdx.x;
+  stack.n = 0;
+  rt::TraceCounters cnt;
+  if (COUNT) memset(&cnt, 0, sizeof(cnt));
+  for (uint64_t g64 = (uint64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x; g64 < total;
+       g64 += (uint64_t)gridDim.x * TRACE_BLOCK) {
+    uint32_t g = (uint32_t)g64;
+    uint32_t s_local = g / npix;
+    uint32_t lp = g - s_local * npix;
+    uint32_t i, j;
+    shard_pixel(sm, lp, &i, &j);
+    rt::Color c = rt::trace_sample<F, COUNT>(sv, rp, i, j, s_begin + s_local, stack, &cnt);
+    double* o = samples + 3 * (size_t)g;
+    o[0] = c.x; o[1] = c.y; o[2] = c.z;
+  }
+  if (COUNT) flush_counters(cnt, counters);
+}
+
+// Persistent waves with path regeneration.  The pass's samples form one index space
+// [0, total); waves pull chunks of it from a global counter and hand indices to their lanes
+// as lanes finish paths: every loop iteration the lanes without a path are compacted with a
+// 64-bit __ballot and ranked with mbcnt (the wavefront prefix sum), take consecutive indices
+// (= consecutive pixels of one sample: coherent camera rays) and start a new path, then ALL
+// lanes advance their path by one bounce.  A lane therefore never idles while the queue has
+// work, whatever the length of its neighbours' paths.  Which lane runs which sample cannot
+// matter: streams are keyed by (pixel, sample) and every sample owns its output slot.
+#define TRACE_CHUNK 512u
+template <uint32_t F>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView sv, rt::RenderParams rp,
+                                                                   ShardMap sm, uint32_t s_begin,
+                                                                   uint32_t total, uint32_t npix,
+                                                                   double* __restrict__ samples,
+                                                                   unsigned int* work_counter) {
+  extern __shared__ int32_t lds_stack[];
+  LdsStack stack;
+  stack.base = lds_stack + threadIdx.x;
+  stack.n = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
+  bool queue_empty = false;               // wave-uniform
+  bool active = false;
+  uint32_t g = 0;
+  rt::PathState ps;
+  for (;;) {
+    unsigned long long need_mask = __ballot(!active);
+    if (need_mask != 0ull) {
+      if (chunk_pos >= chunk_end && !queue_empty) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total) {
+          queue_empty = true;
+        } else {
+          chunk_pos = base;
+          chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
+        }
+      }
+      if (chunk_pos < chunk_end) {
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+        uint32_t n_need = (uint32_t)__popcll(need_mask);
+        uint32_t avail = chunk_end - chunk_pos;
+        if (!active && rank < avail) {
+          g = chunk_pos + rank;
+          uint32_t s_local = g / npix;
+          uint32_t lp = g - s_local * npix;
+          uint32_t i, j;
+          shard_pixel(sm, lp, &i, &j);
+          rt::path_begin(rp, i, j, s_begin + s_local, &ps);
+          active = true;
+        }
+        chunk_pos += (n_need < avail) ? n_need : avail;
+      }
+    }
+    if (__ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
+    if (active) {
+      if (rt::path_step<F, false>(sv, rp, &ps, stack, nullptr)) {
+        double* o = samples + 3 * (size_t)g;
+        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
+        active = false;
+      }
+    }
+  }
+}
+
+// One lane per pixel; samples of the pass are added in ascending sample index.
+__global__ __launch_bounds__(256) void k_reduce_samples(const double* __restrict__ samples,
+                                                        double* __restrict__ accum, uint32_t npix,
+                                                        uint32_t s_count, int first_pass) {
+  uint32_t lp = blockIdx.x * 256u + threadIdx.x;
+  if (lp >= npix) return;
+  double r = 0.0, g = 0.0, b = 0.0;  // world.rs:1210: Vec3::new(0, 0, 0)
+  if (!first_pass) { r = accum[3 * (size_t)lp]; g = accum[3 * (size_t)lp + 1]; b = accum[3 * (size_t)lp + 2]; }
+  for (uint32_t s = 0; s < s_count; ++s) {
+    const double* p = samples + 3 * ((size_t)s * npix + lp);
+    r += p[0]; g += p[1]; b += p[2];  // world.rs:1215 (vec3.rs:223-229 AddAssign)
+  }
+  accum[3 * (size_t)lp] = r; accum[3 * (size_t)lp + 1] = g; accum[3 * (size_t)lp + 2] = b;
+}
+
+__global__ __launch_bounds__(256) void k_tonemap(const double* __restrict__ accum,
+                                                 uint8_t* __restrict__ rgb8, uint32_t npix,
+                                                 uint32_t spp) {
+  uint32_t lp = blockIdx.x * 256u + threadIdx.x;
+  if (lp >= npix) return;
+  int32_t c[3];
+  rt::tone_map(rt::v3(accum[3 * (size_t)lp], accum[3 * (size_t)lp + 1], accum[3 * (size_t)lp + 2]), spp, c);
+  rgb8[3 * (size_t)lp] = (uint8_t)c[0];
+  rgb8[3 * (size_t)lp + 1] = (uint8_t)c[1];
+  rgb8[3 * (size_t)lp + 2] = (uint8_t)c[2];
+}
+
+// ------------------------------------------------------------------ launcher
+static int shard_row_count(int32_t height, const RtxShard& sh, int32_t row_limit) {
+  int n = 0;
+  for (int32_t j = 0; j < height && j < row_limit; ++j)
+    if ((j / sh.block_rows) % sh.shard_count == sh.shard_index) ++n;
+  return n;
+}
+
+static rtx_status validate(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
+                           const RtxShard* shard, RtxShard* sh_out) {
+  if (!s || !cam || !cfg) { set_error("render: NULL scene, camera or config"); return RTX_EINVAL; }
+  if (cfg->threads <= 0 || cfg->image_width <= 0 || cfg->samples_per_pixel <= 0 || cfg->max_depth <= 0) {
+    set_error("render: Config::new asserts threads, image_width, samples_per_pixel, max_depth > 0 (world.rs:36-40)");
+    return RTX_EINVAL;
+  }
+  if (rtx_image_height(cfg) <= 0) { set_error("render: image height <= 0 (Screen::new asserts, screen.rs:14)"); return RTX_EINVAL; }
+  if (!(cam->time1 < cam->time2)) { set_error("render: camera time1 >= time2 (gen_range panics on an empty range, camera.rs:69)"); return RTX_EINVAL; }
+  RtxShard sh = {0, 1, 1, 0};
+  if (shard) sh = *shard;
+  if (sh.shard_count <= 0 || sh.shard_index < 0 || sh.shard_index >= sh.shard_count || sh.block_rows <= 0) {
+    set_error("render: bad shard");
+    return RTX_EINVAL;
+  }
+  *sh_out = sh;
+  return RTX_OK;
+}
+
+static rt::RenderParams make_params(const RtxCamera* cam, const RtxConfig* cfg) {
+  rt::RenderParams rp;
+  static_assert(sizeof(RtxCamera) == sizeof(rt::FlatCamera), "camera layout");
+  memcpy(&rp.cam, cam, sizeof(rt::FlatCamera));
+  rp.background = rt::v3(cfg->background[0], cfg->background[1], cfg->background[2]);
+  rp.image_width = cfg->image_width;
+  rp.image_height = rtx_image_height(cfg);
+  rp.samples_per_pixel = cfg->samples_per_pixel;
+  rp.max_depth = cfg->max_depth;
+  rp.seed = cfg->seed;
+  return rp;
+}
+
+template <bool COUNT>
+static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, const RtxConfig* cfg,
+                              const RtxShard* shard, double* d_accum_out, uint8_t* d_rgb8_out,
+                              hipStream_t stream, RtxRenderStats* stats) {
+  RtxShard sh;
+  rtx_status st = validate(scene, cam, cfg, shard, &sh);
+  if (st != RTX_OK) return st;
+  DeviceScene* ds = scene_device(scene);
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != ds->device) { set_error("render: scene was uploaded to a different device than the current one"); return RTX_EINVAL; }
+
+  const rt::RenderParams rp = make_params(cam, cfg);
+  const int32_t w = rp.image_width, h = rp.image_height;
+  // world.rs:1198-1202: chunk_size = h / threads; rows >= threads * chunk_size are never rendered.
+  int32_t row_limit = h;
+  if (cfg->row_chunk_compat) row_limit = (h / cfg->threads) * cfg->threads;
+  const int rows_all = shard_row_count(h, sh, h);
+  const int rows_active = shard_row_count(h, sh, row_limit);
+  const uint64_t npix_all = (uint64_t)rows_all * w, npix = (uint64_t)rows_active * w;
+  if (npix_all >= (1ull << 31)) { set_error("render: shard larger than 2^31 pixels"); return RTX_EINVAL; }
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (npix_all == 0) return RTX_OK;
+
+  // ---- workspace
+  uint64_t budget = cfg->sample_buffer_bytes ? cfg->sample_buffer_bytes : (6ull << 30);
+  uint64_t per_sample_plane = npix * 24ull;
+  uint32_t spp = (uint32_t)cfg->samples_per_pixel;
+  uint32_t spp_pass = spp;
+  if (per_sample_plane > 0 && (uint64_t)spp * per_sample_plane > budget) {
+    spp_pass = (uint32_t)(budget / per_sample_plane);
+    if (spp_pass < 1) spp_pass = 1;
+  }
+  // a pass's (sample, pixel) index space is addressed with 32-bit indices
+  while (spp_pass > 1 && (uint64_t)spp_pass * npix >= 0xFFFF0000ull) --spp_pass;
+  if ((uint64_t)spp_pass * npix >= 0xFFFF0000ull) { set_error("render: shard too large for one pass"); return RTX_EINVAL; }
+  size_t need_samples = (size_t)spp_pass * per_sample_plane;
+  if (need_samples > ds->samples_bytes) {
+    if (ds->samples) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(ds->samples)); ds->samples = nullptr; ds->samples_bytes = 0; }
+    HIP_TRY(hipMalloc((void**)&ds->samples, need_samples));
+    ds->samples_bytes = need_samples;
+  }
+  double* accum = d_accum_out;
+  if (!accum) {
+    size_t need = (size_t)npix_all * 24;
+    if (need > ds->accum_bytes) {
+      if (ds->accum) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(ds->accum)); ds->accum = nullptr; ds->accum_bytes = 0; }
+      HIP_TRY(hipMalloc((void**)&ds->accum, need));
+      ds->accum_bytes = need;
+    }
+    accum = ds->accum;
+  }
+  if (!ds->counters) HIP_TRY(hipMalloc((void**)&ds->counters, sizeof(rt::TraceCounters)));
+  if (!ds->work_counter) HIP_TRY(hipMalloc((void**)&ds->work_counter, sizeof(unsigned int)));
+  if (!ds->ev[0]) { HIP_TRY(hipEventCreate(&ds->ev[0])); HIP_TRY(hipEventCreate(&ds->ev[1])); }
+  if (COUNT) HIP_TRY(hipMemsetAsync(ds->counters, 0, sizeof(rt::TraceCounters), stream));
+
+  // rows skipped by row_chunk_compat stay (0,0,0) as in the reference's Screen::new
+  if (npix < npix_all) {
+    HIP_TRY(hipMemsetAsync(accum + 3 * npix, 0, (size_t)(npix_all - npix) * 24, stream));
+    if (d_rgb8_out) HIP_TRY(hipMemsetAsync(d_rgb8_out + 3 * npix, 0, (size_t)(npix_all - npix) * 3, stream));
+  }
+
+  ShardMap sm = {w, sh.block_rows, sh.shard_index, sh.shard_count};
+  int stack_levels = ds->view.max_stack + 1;
+  size_t lds_bytes = (size_t)stack_levels * TRACE_BLOCK * sizeof(int32_t);
+  if (lds_bytes > 64 * 1024) { set_error("render: BVH too deep for the LDS traversal stack"); return RTX_EUNSUPPORTED; }
+  const uint32_t feat = ds->view.features;
+  const int preset = ((feat & ~P_SPHERES) == 0) ? 0 : (((feat & ~P_MESH) == 0) ? 1 : 2);
+  const bool use_simple = COUNT || ds->force_simple;
+
+  float trace_ms = 0.f;
+  int passes = 0;
+  if (npix > 0) {
+    for (uint32_t s_begin = 0; s_begin < spp; s_begin += spp_pass, ++passes) {
+      uint32_t s_count = spp - s_begin < spp_pass ? spp - s_begin : spp_pass;
+      uint32_t total = (uint32_t)((uint64_t)s_count * npix);
+      if (stats) HIP_TRY(hipEventRecord(ds->ev[0], stream));
+      if (use_simple) {
+        uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu * 8 ? want : (uint64_t)ds->n_cu * 8);
+#define LAUNCH_SIMPLE(FEAT)                                                                          \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_simple<FEAT, COUNT>), dim3(grid), dim3(TRACE_BLOCK),     \
+                     lds_bytes, stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, \
+                     ds->counters)
+        if (COUNT) { LAUNCH_SIMPLE(P_ALL); }
+        else if (preset == 0) { LAUNCH_SIMPLE(P_SPHERES); }
+        else if (preset == 1) { LAUNCH_SIMPLE(P_MESH); }
+        else { LAUNCH_SIMPLE(P_ALL); }
+#undef LAUNCH_SIMPLE
+      } else {
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->blocks_per_cu[preset];
+        uint32_t grid = (uint32_t)(want < resident ? want : resident);
+#define LAUNCH_PERSISTENT(FEAT)                                                                       \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_persistent<FEAT>), dim3(grid), dim3(TRACE_BLOCK),        \
+                     lds_bytes, stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, \
+                     ds->work_counter)
+        if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES); }
+        else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH); }
+        else { LAUNCH_PERSISTENT(P_ALL); }
+#undef LAUNCH_PERSISTENT
+      }
+      HIP_TRY(hipGetLastError());
+      if (stats) {
+        HIP_TRY(hipEventRecord(ds->ev[1], stream));
+        HIP_TRY(hipEventSynchronize(ds->ev[1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ds->ev[0], ds->ev[1]));
+        trace_ms += ms;
+      }
+      uint32_t pgrid = (uint32_t)((npix + 255) / 256);
+      hipLaunchKernelGGL(k_reduce_samples, dim3(pgrid), dim3(256), 0, stream, ds->samples, accum,
+                         (uint32_t)npix, s_count, s_begin == 0 ? 1 : 0);
+      HIP_TRY(hipGetLastError());
+    }
+    if (d_rgb8_out) {
+      uint32_t pgrid = (uint32_t)((npix + 255) / 256);
+      hipLaunchKernelGGL(k_tonemap, dim3(pgrid), dim3(256), 0, stream, accum, d_rgb8_out, (uint32_t)npix, spp);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (stats) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    stats->trace_ms = trace_ms;
+    stats->trace_launches = passes;
+    stats->passes = passes;
+    stats->sample_buffer_bytes = need_samples;
+    if (COUNT) {
+      rt::TraceCounters c;
+      HIP_TRY(hipMemcpy(&c, ds->counters, sizeof(c), hipMemcpyDeviceToHost));
+      stats->samples = c.samples; stats->rays = c.rays; stats->box_tests = c.box_tests;
+      stats->sphere_tests = c.sphere_tests; stats->moving_sphere_tests = c.moving_sphere_tests;
+      stats->rect_tests = c.rect_tests; stats->triangle_tests = c.triangle_tests;
+      stats->scatters = c.scatters; stats->texels = c.texels; stats->perlin_calls = c.perlin_calls;
+    }
+  }
+  return RTX_OK;
+}
+
+}  // namespace rtx
+
+using namespace rtx;
+
+extern "C" {
+
+rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
+  if (!f || !out) { set_error("rtx_scene_upload: NULL argument"); return RTX_EINVAL; }
+  *out = nullptr;
+  const FlatScene& fs = *flat_of(f);
+  DeviceScene* ds = new (std::nothrow) DeviceScene();
+  if (!ds) { set_error("out of memory"); return RTX_ENOMEM; }
+  hipError_t e = hipGetDevice(&ds->device);
+  if (e != hipSuccess) {
+    set_error(std::string("hipGetDevice: ") + hipGetErrorString(e) + " (this library has no CPU render path)");
+    delete ds;
+    return RTX_EHIP;
+  }
+  rt::SceneView& v = ds->view;
+  memset(&v, 0, sizeof(v));
+  rtx_status st;
+#define UP(field, vec) if ((st = upload_array(ds, fs.vec, &v.field)) != RTX_OK) { free_device_scene(ds); return st; }
+  UP(spheres, spheres) UP(moving_spheres, moving_spheres) UP(rects, rects) UP(triangles, triangles)
+  UP(nodes, nodes) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
+  UP(materials, materials) UP(textures, textures) UP(perlins, perlins) UP(images, images) UP(texels, texels)
+#undef UP
+  v.n_top_level = (int32_t)fs.top_level.size();
+  v.max_stack = fs.max_stack;
+  v.features = fs.features;
+  ds->n_nodes = (int32_t)fs.nodes.size();
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0)
+      ds->n_cu = prop.multiProcessorCount;
+    size_t lds = (size_t)(fs.max_stack + 1) * TRACE_BLOCK * sizeof(int32_t);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
+    const char* k = getenv("RTX_TRACE_KERNEL");
+    ds->force_simple = (k && strcmp(k, "simple") == 0);
+  }
+  *out = make_scene_handle(ds);
+  return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* s) {
+  if (!s) return;
+  free_device_scene(scene_device(s));
+  free_scene_handle(s);
+}
+
+rtx_status rtx_render_device(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
+                             const RtxShard* shard, double* d_accum_rgb, uint8_t* d_rgb8,
+                             void* hip_stream, RtxRenderStats* stats) {
+  return render_impl<false>(s, cam, cfg, shard, d_accum_rgb, d_rgb8, (hipStream_t)hip_stream, stats);
+}
+
+rtx_status rtx_render_count(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
+                            const RtxShard* shard, RtxRenderStats* stats) {
+  if (!stats) { set_error("rtx_render_count: stats is NULL"); return RTX_EINVAL; }
+  return render_impl<true>(s, cam, cfg, shard, nullptr, nullptr, (hipStream_t) nullptr, stats);
+}
+
+rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out) {
+  if (!out) { set_error("rtx_render: NULL frame"); return RTX_EINVAL; }
+  RtxShard sh;
+  rtx_status st = validate(s, cam, cfg, nullptr, &sh);
+  if (st != RTX_OK) return st;
+  size_t npix = (size_t)cfg->image_width * (size_t)rtx_image_height(cfg);
+  double* d_accum = nullptr;
+  uint8_t* d_rgb = nullptr;
+  if (hipMalloc((void**)&d_accum, npix * 24) != hipSuccess || hipMalloc((void**)&d_rgb, npix * 3) != hipSuccess) {
+    if (d_accum) (void)hipFree(d_accum);
+    set_error("rtx_render: hipMalloc of the frame failed");
+    return RTX_EHIP;
+  }
+  st = render_impl<false>(s, cam, cfg, nullptr, d_accum, d_rgb, (hipStream_t) nullptr, nullptr);
+  if (st == RTX_OK) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && out->accum_rgb) e = hipMemcpy(out->accum_rgb, d_accum, npix * 24, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out->rgb8) e = hipMemcpy(out->rgb8, d_rgb, npix * 3, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error(std::string("rtx_render: ") + hipGetErrorString(e)); st = RTX_EHIP; }
+  }
+  (void)hipFree(d_accum);
+  (void)hipFree(d_rgb);
+  return st;
+}
+
+}  // extern "C"

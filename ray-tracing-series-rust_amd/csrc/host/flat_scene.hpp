@@ -1,0 +1,73 @@
+// Host-owned flattened scene (`rtx_flat` behind the C ABI): the arrays of
+// core/flat_types.hpp in std::vectors, plus build statistics.
+#pragma once
+#include <string>
+#include <vector>
+#include "../core/flat_types.hpp"
+#include "scene_graph.hpp"
+
+namespace rtx {
+
+struct FlatScene {
+  std::vector<rt::FlatSphere> spheres;
+  std::vector<rt::FlatMovingSphere> moving_spheres;
+  std::vector<rt::FlatRect> rects;
+  std::vector<rt::FlatTriangle> triangles;
+  std::vector<rt::FlatNode> nodes;
+  std::vector<rt::PrimRef> refs;
+  std::vector<rt::FlatEntry> entries;
+  std::vector<int32_t> top_level;
+  std::vector<rt::FlatMaterial> materials;
+  std::vector<rt::FlatTexture> textures;
+  std::vector<rt::FlatPerlin> perlins;
+  std::vector<rt::FlatImage> images;
+  std::vector<double> texels;
+  int32_t max_stack = 0;      // deepest BVH (number of stacked far children a walk can hold)
+  int32_t n_bvh = 0;
+  uint32_t features = 0;      // rt::Feature bits reachable in this scene
+  double sah_cost = 0.0;      // summed SAH cost of all BVHs (diagnostic)
+
+  // pointers into the vectors above (host memory)
+  rt::SceneView view() const {
+    rt::SceneView v;
+    v.spheres = spheres.data();
+    v.moving_spheres = moving_spheres.data();
+    v.rects = rects.data();
+    v.triangles = triangles.data();
+    v.nodes = nodes.data();
+    v.refs = refs.data();
+    v.entries = entries.data();
+    v.top_level = top_level.data();
+    v.materials = materials.data();
+    v.textures = textures.data();
+    v.perlins = perlins.data();
+    v.images = images.data();
+    v.texels = texels.data();
+    v.n_top_level = (int32_t)top_level.size();
+    v.max_stack = max_stack;
+    v.features = features;
+    v.pad = 0;
+    return v;
+  }
+  size_t total_bytes() const;
+};
+
+struct BuildOptions {
+  int max_leaf = 2;   // primitives per BVH leaf (1..8)
+  int sah_bins = 32;
+};
+
+// Flatten `world` (any Hittable handle of `g`).  Returns false and sets *err when the graph
+// uses a nesting the kernels do not implement ("scene shapes").
+bool flatten_scene(const SceneGraph& g, int32_t world, const BuildOptions& opt, FlatScene* out,
+                   std::string* err);
+
+// Binned-SAH BVH over axis-aligned boxes.  boxes = 6 doubles (min xyz, max xyz) per
+// primitive.  Emits nodes (appended to *nodes, child indices absolute) and the
+// permutation `order` (slot -> input primitive).  Returns the root node index, or -1 if
+// n < 2 (the caller emits a GROUP instead).  *depth = the stack depth a walk needs.
+int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
+                  std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order, int32_t* depth,
+                  double* sah_cost);
+
+}  // namespace rtx

@@ -1,0 +1,342 @@
+// Scene graph -> flat arrays (see core/flat_types.hpp for the layout).
+//
+// Shapes accepted (everything the reference's scene catalogue builds,
+// /root/reference/src/world.rs:95-874):
+//   world      := LIST | any single object
+//   LIST item  := primitive | RECT_PRISM | LIST (inlined: list-in-list hits are order
+//                 equivalent to the inlined sequence) | BVH | XFORM chain | CONSTANT_MEDIUM
+//   BVH item   := primitive | RECT_PRISM (its 6 rects become BVH primitives) | LIST (inlined)
+//   XFORM      := up to RT_MAX_XFORM_OPS nested Translate / RotateY over
+//                 primitive | RECT_PRISM | LIST of primitives | BVH
+//   MEDIUM     := boundary is any of the above except another medium; media only at top level
+// Anything else is reported as unsupported rather than approximated.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "../core/geometry.hpp"
+#include "flat_scene.hpp"
+
+namespace rtx {
+
+using rt::Vec3;
+
+size_t FlatScene::total_bytes() const {
+  return spheres.size() * sizeof(rt::FlatSphere) + moving_spheres.size() * sizeof(rt::FlatMovingSphere) +
+         rects.size() * sizeof(rt::FlatRect) + triangles.size() * sizeof(rt::FlatTriangle) +
+         nodes.size() * sizeof(rt::FlatNode) + refs.size() * sizeof(rt::PrimRef) +
+         entries.size() * sizeof(rt::FlatEntry) + top_level.size() * sizeof(int32_t) +
+         materials.size() * sizeof(rt::FlatMaterial) + textures.size() * sizeof(rt::FlatTexture) +
+         perlins.size() * sizeof(rt::FlatPerlin) + images.size() * sizeof(rt::FlatImage) +
+         texels.size() * sizeof(double);
+}
+
+namespace {
+
+struct Flattener {
+  const SceneGraph& g;
+  FlatScene& out;
+  BuildOptions opt;
+  std::string err;
+  std::vector<int64_t> prim_of;  // graph hittable -> PrimRef already emitted (-1: not yet)
+
+  Flattener(const SceneGraph& gg, FlatScene& o, const BuildOptions& op)
+      : g(gg), out(o), opt(op), prim_of(gg.hittables.size(), -1) {}
+
+  bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+
+  static bool is_prim(int32_t kind) {
+    return kind == H_SPHERE || kind == H_MOVING_SPHERE || kind == H_TRIANGLE || kind == H_XY_RECT ||
+           kind == H_XZ_RECT || kind == H_YZ_RECT;
+  }
+
+  rt::PrimRef emit_rect(int32_t axis, double a0, double a1, double b0, double b1, double k, int32_t mat) {
+    rt::FlatRect q;
+    q.a0 = a0; q.a1 = a1; q.b0 = b0; q.b1 = b1; q.k = k; q.axis = axis; q.mat = mat;
+    out.rects.push_back(q);
+    return rt::make_primref(rt::PRIM_RECT, (uint32_t)out.rects.size() - 1);
+  }
+
+  rt::PrimRef emit_prim(int32_t h) {
+    if (prim_of[h] >= 0) return (rt::PrimRef)prim_of[h];
+    const GHittable& o = g.hittables[h];
+    rt::PrimRef ref = 0;
+    switch (o.kind) {
+      case H_SPHERE: {
+        rt::FlatSphere s;
+        s.cx = o.f[0]; s.cy = o.f[1]; s.cz = o.f[2]; s.radius = o.f[3]; s.mat = o.mat; s.pad = 0;
+        out.spheres.push_back(s);
+        ref = rt::make_primref(rt::PRIM_SPHERE, (uint32_t)out.spheres.size() - 1);
+        break;
+      }
+      case H_MOVING_SPHERE: {
+        rt::FlatMovingSphere s;
+        for (int i = 0; i < 3; ++i) { s.c0[i] = o.f[i]; s.c1[i] = o.f[3 + i]; }
+        s.time0 = o.f[6]; s.time1 = o.f[7]; s.radius = o.f[8]; s.mat = o.mat; s.pad = 0;
+        out.moving_spheres.push_back(s);
+        ref = rt::make_primref(rt::PRIM_MOVING_SPHERE, (uint32_t)out.moving_spheres.size() - 1);
+        break;
+      }
+      case H_TRIANGLE: {
+        rt::FlatTriangle t;
+        for (int i = 0; i < 3; ++i) { t.v0[i] = o.f[i]; t.v1[i] = o.f[3 + i]; t.v2[i] = o.f[6 + i]; t.normal[i] = o.f[9 + i]; }
+        t.mat = o.mat; t.pad = 0;
+        out.triangles.push_back(t);
+        ref = rt::make_primref(rt::PRIM_TRIANGLE, (uint32_t)out.triangles.size() - 1);
+        break;
+      }
+      case H_XY_RECT: ref = emit_rect(rt::RECT_XY, o.f[0], o.f[1], o.f[2], o.f[3], o.f[4], o.mat); break;
+      case H_XZ_RECT: ref = emit_rect(rt::RECT_XZ, o.f[0], o.f[1], o.f[2], o.f[3], o.f[4], o.mat); break;
+      default: ref = emit_rect(rt::RECT_YZ, o.f[0], o.f[1], o.f[2], o.f[3], o.f[4], o.mat); break;
+    }
+    prim_of[h] = (int64_t)ref;
+    return ref;
+  }
+
+  // RectPrism::new (hit.rs:720-769): six sides in the reference's add() order.
+  void emit_prism(const GHittable& o, std::vector<rt::PrimRef>* refs) {
+    const double* p0 = &o.f[0];
+    const double* p1 = &o.f[3];
+    refs->push_back(emit_rect(rt::RECT_XY, p0[0], p1[0], p0[1], p1[1], p1[2], o.mat));
+    refs->push_back(emit_rect(rt::RECT_XY, p0[0], p1[0], p0[1], p1[1], p0[2], o.mat));
+    refs->push_back(emit_rect(rt::RECT_XZ, p0[0], p1[0], p0[2], p1[2], p1[1], o.mat));
+    refs->push_back(emit_rect(rt::RECT_XZ, p0[0], p1[0], p0[2], p1[2], p0[1], o.mat));
+    refs->push_back(emit_rect(rt::RECT_YZ, p0[1], p1[1], p0[2], p1[2], p1[0], o.mat));
+    refs->push_back(emit_rect(rt::RECT_YZ, p0[1], p1[1], p0[2], p1[2], p0[0], o.mat));
+  }
+
+  // Primitives of h in list order; lists and prisms are inlined.
+  bool collect_prims(int32_t h, std::vector<rt::PrimRef>* refs, int depth = 0) {
+    if (depth > 64) return fail("hittable lists nested deeper than 64");
+    const GHittable& o = g.hittables[h];
+    if (is_prim(o.kind)) { refs->push_back(emit_prim(h)); return true; }
+    if (o.kind == H_RECT_PRISM) { emit_prism(o, refs); return true; }
+    if (o.kind == H_LIST) {
+      for (int32_t c : o.children)
+        if (!collect_prims(c, refs, depth + 1)) return false;
+      return true;
+    }
+    return fail("unsupported nesting: only primitives, RectPrism and lists of those may sit inside a BVH or a transformed/medium list");
+  }
+
+  // Reference bounding boxes (hit.rs bounding_box impls) of one flattened primitive.
+  void prim_box(rt::PrimRef ref, double time0, double time1, double* b) const {
+    uint32_t idx = rt::primref_index(ref);
+    switch (rt::primref_type(ref)) {
+      case rt::PRIM_SPHERE: {  // hit.rs:239-244
+        const rt::FlatSphere& s = out.spheres[idx];
+        Vec3 c = rt::v3(s.cx, s.cy, s.cz), r = rt::v3(s.radius, s.radius, s.radius);
+        Vec3 lo = c - r, hi = c + r;
+        b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+        break;
+      }
+      case rt::PRIM_MOVING_SPHERE: {  // hit.rs:317-327
+        const rt::FlatMovingSphere& s = out.moving_spheres[idx];
+        Vec3 r = rt::v3(s.radius, s.radius, s.radius);
+        Vec3 ca = rt::moving_sphere_center(s, time0), cb = rt::moving_sphere_center(s, time1);
+        Vec3 lo0 = ca - r, hi0 = ca + r, lo1 = cb - r, hi1 = cb + r;
+        b[0] = std::fmin(lo0.x, lo1.x); b[1] = std::fmin(lo0.y, lo1.y); b[2] = std::fmin(lo0.z, lo1.z);
+        b[3] = std::fmax(hi0.x, hi1.x); b[4] = std::fmax(hi0.y, hi1.y); b[5] = std::fmax(hi0.z, hi1.z);
+        break;
+      }
+      case rt::PRIM_RECT: {  // hit.rs:503-508, 568-573, 633-638 (+-0.0001 on the thin axis)
+        const rt::FlatRect& q = out.rects[idx];
+        if (q.axis == rt::RECT_XY) { b[0] = q.a0; b[1] = q.b0; b[2] = q.k - 0.0001; b[3] = q.a1; b[4] = q.b1; b[5] = q.k + 0.0001; }
+        else if (q.axis == rt::RECT_XZ) { b[0] = q.a0; b[1] = q.k - 0.0001; b[2] = q.b0; b[3] = q.a1; b[4] = q.k + 0.0001; b[5] = q.b1; }
+        else { b[0] = q.k - 0.0001; b[1] = q.a0; b[2] = q.b0; b[3] = q.k + 0.0001; b[4] = q.a1; b[5] = q.b1; }
+        break;
+      }
+      default: {  // hit.rs:164-177
+        const rt::FlatTriangle& t = out.triangles[idx];
+        for (int a = 0; a < 3; ++a) {
+          b[a] = std::fmin(std::fmin(t.v0[a], t.v1[a]), t.v2[a]);
+          b[3 + a] = std::fmax(std::fmax(t.v0[a], t.v1[a]), t.v2[a]);
+        }
+        break;
+      }
+    }
+  }
+
+  int32_t push_entry(const rt::FlatEntry& e) {
+    out.entries.push_back(e);
+    return (int32_t)out.entries.size() - 1;
+  }
+  static rt::FlatEntry blank_entry(int32_t kind) {
+    rt::FlatEntry e;
+    memset(&e, 0, sizeof(e));
+    e.kind = kind;
+    return e;
+  }
+
+  int32_t emit_group(const std::vector<rt::PrimRef>& refs) {
+    rt::FlatEntry e = blank_entry(rt::ENTRY_GROUP);
+    e.a = (int32_t)out.refs.size();
+    e.b = (int32_t)refs.size();
+    out.refs.insert(out.refs.end(), refs.begin(), refs.end());
+    return push_entry(e);
+  }
+
+  // PRIM / GROUP / BVH entry for h; -1 on failure.
+  int32_t emit_geom_entry(int32_t h) {
+    const GHittable& o = g.hittables[h];
+    if (is_prim(o.kind)) {
+      rt::FlatEntry e = blank_entry(rt::ENTRY_PRIM);
+      e.a = (int32_t)emit_prim(h);
+      return push_entry(e);
+    }
+    if (o.kind == H_RECT_PRISM || o.kind == H_LIST) {
+      std::vector<rt::PrimRef> refs;
+      if (!collect_prims(h, &refs)) return -1;
+      if (refs.empty()) { fail("empty HittableList under a transform/medium"); return -1; }
+      return emit_group(refs);
+    }
+    if (o.kind == H_BVH) {
+      std::vector<rt::PrimRef> refs;
+      for (int32_t c : o.children)
+        if (!collect_prims(c, &refs)) return -1;
+      if (refs.size() < 2) return emit_group(refs);
+      std::vector<double> boxes(6 * refs.size());
+      for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], o.f[0], o.f[1], &boxes[6 * i]);
+      std::vector<uint32_t> order;
+      int32_t depth = 0;
+      int32_t root = build_bvh(boxes, opt, &out.nodes, &order, &depth, &out.sah_cost);
+      rt::FlatEntry e = blank_entry(rt::ENTRY_BVH);
+      e.a = root;
+      e.b = (int32_t)out.refs.size();
+      e.c = (int32_t)refs.size();
+      for (size_t i = 0; i < refs.size(); ++i) out.refs.push_back(refs[order[i]]);
+      out.max_stack = std::max(out.max_stack, depth);
+      out.n_bvh++;
+      return push_entry(e);
+    }
+    fail("unsupported object where geometry is expected (transform of a transform chain > 2, medium inside a wrapper, ...)");
+    return -1;
+  }
+
+  // Any non-medium entry, including Translate/RotateY chains.
+  int32_t emit_solid_entry(int32_t h) {
+    const GHittable& o = g.hittables[h];
+    if (o.kind != H_TRANSLATE && o.kind != H_ROTATE_Y) {
+      if (o.kind == H_CONSTANT_MEDIUM) { fail("a ConstantMedium may only appear in the top-level list"); return -1; }
+      return emit_geom_entry(h);
+    }
+    rt::FlatEntry e = blank_entry(rt::ENTRY_XFORM);
+    int32_t cur = h;
+    int nops = 0;
+    while (g.hittables[cur].kind == H_TRANSLATE || g.hittables[cur].kind == H_ROTATE_Y) {
+      if (nops == RT_MAX_XFORM_OPS) { fail("more than 2 nested Translate/RotateY wrappers"); return -1; }
+      const GHittable& w = g.hittables[cur];
+      rt::FlatXformOp& op = e.ops[nops++];
+      if (w.kind == H_TRANSLATE) { op.op = rt::XFORM_TRANSLATE; op.v[0] = w.f[0]; op.v[1] = w.f[1]; op.v[2] = w.f[2]; }
+      else { op.op = rt::XFORM_ROTATE_Y; op.v[0] = w.f[0]; op.v[1] = w.f[1]; op.v[2] = 0.0; }
+      cur = w.children[0];
+    }
+    int32_t child = emit_geom_entry(cur);
+    if (child < 0) return -1;
+    e.a = child;
+    e.b = nops;
+    return push_entry(e);
+  }
+
+  int32_t emit_entry(int32_t h) {
+    const GHittable& o = g.hittables[h];
+    if (o.kind != H_CONSTANT_MEDIUM) return emit_solid_entry(h);
+    int32_t boundary = emit_solid_entry(o.children[0]);
+    if (boundary < 0) return -1;
+    rt::FlatEntry e = blank_entry(rt::ENTRY_MEDIUM);
+    e.a = boundary;
+    e.b = o.mat;
+    e.f[0] = o.f[0];
+    return push_entry(e);
+  }
+
+  bool emit_top(int32_t h, int depth = 0) {
+    if (depth > 64) return fail("hittable lists nested deeper than 64");
+    const GHittable& o = g.hittables[h];
+    if (o.kind == H_LIST) {
+      for (int32_t c : o.children)
+        if (!emit_top(c, depth + 1)) return false;
+      return true;
+    }
+    int32_t e = emit_entry(h);
+    if (e < 0) return false;
+    out.top_level.push_back(e);
+    return true;
+  }
+
+  bool texture_has_image(int32_t t, int depth = 0) const {
+    if (t < 0 || depth > 16) return false;
+    const GTexture& tx = g.textures[t];
+    if (tx.kind == rt::TEX_IMAGE) return true;
+    if (tx.kind == rt::TEX_CHECKER) return texture_has_image(tx.a, depth + 1) || texture_has_image(tx.b, depth + 1);
+    return false;
+  }
+
+  bool run(int32_t world) {
+    for (const GTexture& t : g.textures) {
+      rt::FlatTexture f;
+      memset(&f, 0, sizeof(f));
+      f.kind = t.kind; f.a = t.a; f.b = t.b;
+      f.color[0] = t.color[0]; f.color[1] = t.color[1]; f.color[2] = t.color[2];
+      f.scale = t.scale;
+      out.textures.push_back(f);
+    }
+    for (const GMaterial& m : g.materials) {
+      rt::FlatMaterial f;
+      memset(&f, 0, sizeof(f));
+      f.kind = m.kind; f.tex = m.tex;
+      f.albedo[0] = m.albedo[0]; f.albedo[1] = m.albedo[1]; f.albedo[2] = m.albedo[2];
+      f.param = m.param;
+      f.needs_uv = texture_has_image(m.tex) ? 1 : 0;
+      out.materials.push_back(f);
+    }
+    out.perlins = g.perlins;
+    for (const GImage& im : g.images) {
+      rt::FlatImage f;
+      f.width = im.width; f.height = im.height;
+      f.first_texel = (int64_t)(out.texels.size() / 3);
+      out.texels.insert(out.texels.end(), im.texels.begin(), im.texels.end());
+      out.images.push_back(f);
+    }
+    // An empty world is legal: HittableList::hit returns None and every path sees the background.
+    if (!emit_top(world)) return false;
+    uint32_t f = 0;
+    if (!out.spheres.empty()) f |= rt::F_SPHERE;
+    if (!out.moving_spheres.empty()) f |= rt::F_MOVING_SPHERE;
+    if (!out.rects.empty()) f |= rt::F_RECT;
+    if (!out.triangles.empty()) f |= rt::F_TRIANGLE;
+    for (const rt::FlatEntry& e : out.entries) {
+      if (e.kind == rt::ENTRY_PRIM) f |= rt::F_PRIM_ENTRY;
+      else if (e.kind == rt::ENTRY_GROUP) f |= rt::F_GROUP;
+      else if (e.kind == rt::ENTRY_BVH) f |= rt::F_BVH;
+      else if (e.kind == rt::ENTRY_XFORM) f |= rt::F_XFORM;
+      else if (e.kind == rt::ENTRY_MEDIUM) f |= rt::F_MEDIUM;
+    }
+    for (const rt::FlatMaterial& m : out.materials) {
+      if (m.kind == rt::MAT_LAMBERTIAN) f |= rt::F_LAMBERTIAN;
+      else if (m.kind == rt::MAT_METAL) f |= rt::F_METAL;
+      else if (m.kind == rt::MAT_DIELECTRIC) f |= rt::F_DIELECTRIC;
+      else if (m.kind == rt::MAT_DIFFUSE_LIGHT) f |= rt::F_LIGHT;
+      else if (m.kind == rt::MAT_ISOTROPIC) f |= rt::F_ISOTROPIC;
+    }
+    for (const rt::FlatTexture& t : out.textures) {
+      if (t.kind == rt::TEX_CHECKER) f |= rt::F_CHECKER;
+      else if (t.kind == rt::TEX_NOISE) f |= rt::F_NOISE;
+      else if (t.kind == rt::TEX_IMAGE) f |= rt::F_IMAGE;
+    }
+    out.features = f;
+    return true;
+  }
+};
+
+}  // namespace
+
+bool flatten_scene(const SceneGraph& g, int32_t world, const BuildOptions& opt, FlatScene* out,
+                   std::string* err) {
+  if (!g.valid_hittable(world)) { *err = "flatten: bad world handle"; return false; }
+  *out = FlatScene();
+  Flattener f(g, *out, opt);
+  if (!f.run(world)) { *err = f.err; return false; }
+  return true;
+}
+
+}  // namespace rtx
