@@ -128,6 +128,8 @@ ABI = {
     "rtx_render_count": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.POINTER(RtxShard),
                                      C.POINTER(RtxRenderStats)]),
     "rtx_write_ppm": (C.c_int32, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "rtx_device_math": (C.c_int32, [C.c_int32, _D3, _D3, C.c_int64, _D3]),
+    "rtx_device_stream": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int32, _D3]),
     "rtx_builder_graph": (_VP, [_VP]),
     "rtx_flat_arrays": (_VP, [_VP]),
 }
@@ -404,6 +406,22 @@ class Scene:
         stats = RtxRenderStats()
         _check(lib.rtx_render_count(self._p, C.byref(cam), C.byref(cfg), C.byref(sh) if sh else None, C.byref(stats)))
         return stats
+
+
+def device_math(fn, x, y=None):
+    """Evaluate one arithmetic building block on the GPU (see rtx_device_math)."""
+    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6, "div": 7, "muladd": 8, "floor": 9}
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y if y is not None else np.ones_like(x), dtype=np.float64)
+    out = np.empty_like(x)
+    _check(lib.rtx_device_math(names[fn], x.ctypes.data_as(_D3), y.ctypes.data_as(_D3), x.size, out.ctypes.data_as(_D3)))
+    return out
+
+
+def device_stream(seed, pixel, sample, n):
+    out = np.empty(n, dtype=np.float64)
+    _check(lib.rtx_device_stream(seed, pixel, sample, n, out.ctypes.data_as(_D3)))
+    return out
 
 
 def shard_rows(cfg, shard):

@@ -252,6 +252,31 @@ __global__ __launch_bounds__(256) void k_tonemap(const double* __restrict__ accu
   rgb8[3 * (size_t)lp + 2] = (uint8_t)c[2];
 }
 
+// Device self-test kernels (rtx_device_math / rtx_device_stream).
+__global__ void k_device_math(int fn, const double* x, const double* y, long long n, double* out) {
+  long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double a = x[k], b = y[k], r;
+  switch (fn) {
+    case 0: r = rt::rt_sin(a); break;
+    case 1: r = rt::rt_cos(a); break;
+    case 2: r = rt::rt_log(a); break;
+    case 3: r = rt::rt_acos(a); break;
+    case 4: r = rt::rt_atan2(a, b); break;
+    case 5: r = rt::rt_tan(a); break;
+    case 6: r = rt::rt_sqrt(a); break;
+    case 7: r = a / b; break;
+    case 8: r = a * b + a; break;
+    default: r = rt::rt_floor(a); break;
+  }
+  out[k] = r;
+}
+__global__ void k_device_stream(unsigned long long seed, unsigned long long pixel, unsigned int sample, int n, double* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  rt::Rng g = rt::rng_for_sample(seed, pixel, sample);
+  for (int k = 0; k < n; ++k) out[k] = rt::rng_f64(g);
+}
+
 // ------------------------------------------------------------------ launcher
 static int shard_row_count(int32_t height, const RtxShard& sh, int32_t row_limit) {
   int n = 0;
@@ -495,6 +520,42 @@ rtx_status rtx_render_count(const rtx_scene* s, const RtxCamera* cam, const RtxC
                             const RtxShard* shard, RtxRenderStats* stats) {
   if (!stats) { set_error("rtx_render_count: stats is NULL"); return RTX_EINVAL; }
   return render_impl<true>(s, cam, cfg, shard, nullptr, nullptr, (hipStream_t) nullptr, stats);
+}
+
+rtx_status rtx_device_math(int32_t fn, const double* x, const double* y, int64_t n, double* out) {
+  if (!x || !y || !out || n < 0) { set_error("rtx_device_math: bad argument"); return RTX_EINVAL; }
+  if (n == 0) return RTX_OK;
+  double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  size_t bytes = (size_t)n * sizeof(double);
+  rtx_status st = RTX_OK;
+  auto fail = [&](const char* what, hipError_t e) { set_error(std::string(what) + ": " + hipGetErrorString(e)); st = RTX_EHIP; };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&dx, bytes)) != hipSuccess) fail("hipMalloc", e);
+  if (st == RTX_OK && (e = hipMalloc((void**)&dy, bytes)) != hipSuccess) fail("hipMalloc", e);
+  if (st == RTX_OK && (e = hipMalloc((void**)&dout, bytes)) != hipSuccess) fail("hipMalloc", e);
+  if (st == RTX_OK && (e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", e);
+  if (st == RTX_OK && (e = hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", e);
+  if (st == RTX_OK) {
+    hipLaunchKernelGGL(k_device_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (int)fn, dx, dy, (long long)n, dout);
+    if ((e = hipGetLastError()) != hipSuccess) fail("k_device_math", e);
+  }
+  if (st == RTX_OK && (e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost)) != hipSuccess) fail("hipMemcpy", e);
+  if (dx) (void)hipFree(dx);
+  if (dy) (void)hipFree(dy);
+  if (dout) (void)hipFree(dout);
+  return st;
+}
+
+rtx_status rtx_device_stream(uint64_t seed, uint64_t pixel, uint32_t sample, int32_t n, double* out) {
+  if (!out || n < 0) { set_error("rtx_device_stream: bad argument"); return RTX_EINVAL; }
+  if (n == 0) return RTX_OK;
+  double* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+  hipLaunchKernelGGL(k_device_stream, dim3(1), dim3(64), 0, 0, (unsigned long long)seed, (unsigned long long)pixel, (unsigned int)sample, (int)n, d);
+  hipError_t e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_error(std::string("rtx_device_stream: ") + hipGetErrorString(e)); return RTX_EHIP; }
+  return RTX_OK;
 }
 
 rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out) {

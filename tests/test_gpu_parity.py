@@ -1,0 +1,105 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle, bit for bit.
+
+Tolerance: 0.  All arithmetic on the path is f64 with identical operation order on both sides
+(-ffp-contract=off, IEEE div/sqrt, shared deterministic libm), so accumulators must be EQUAL, which
+is stronger than the north-star bound (per-pixel L2 < 1e-4).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# (scene id, image width, image aspect, spp, scene options)
+CASES = [
+    ("book1_canonical_C1", 100, 200, 3.0 / 2.0, 10, {}),   # BASELINE configs[0]: 200x133, 10 spp, depth 50
+    ("book1_head", 13, 160, 16.0 / 9.0, 8, {}),
+    ("checkered", 0, 96, 16.0 / 9.0, 8, {}),
+    ("two_perlin", 1, 96, 16.0 / 9.0, 8, {}),
+    ("earth", 2, 96, 16.0 / 9.0, 8, {}),
+    ("simple_light", 3, 96, 16.0 / 9.0, 8, {}),
+    ("cornell_box", 4, 80, 1.0, 8, {}),
+    ("cornell_smoke", 5, 80, 1.0, 8, {}),
+    ("book2_final", 6, 100, 1.0, 8, {}),
+    ("moving_test", 7, 96, 16.0 / 9.0, 8, {}),
+    ("benchmark_test", 9, 96, 16.0 / 9.0, 4, {}),
+    ("triangle_test", 10, 96, 16.0 / 9.0, 8, {}),
+    ("dragon_mesh_50k", 11, 120, 16.0 / 9.0, 4, {"mesh_triangles": 50000}),
+    ("triangular_prism", 12, 80, 1.0, 8, {}),
+    ("empty_world", 101, 32, 16.0 / 9.0, 2, {}),
+]
+
+
+def _setup(rtsr, sid, width, aspect, spp, opts, seed=3):
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(sid, **opts)
+    cfg = rtsr.Config.new(aspect, width, spp, 50, 10, seed=seed, background=bg)
+    flat = b.flatten(world)
+    return b, world, cam, cfg, flat
+
+
+@pytest.mark.parametrize("name,sid,width,aspect,spp,opts", CASES, ids=[c[0] for c in CASES])
+def test_gpu_equals_oracle(rtsr, orc, name, sid, width, aspect, spp, opts):
+    b, world, cam, cfg, flat = _setup(rtsr, sid, width, aspect, spp, opts)
+    h = rtsr.image_height(cfg)
+    scene = flat.upload()
+    screen = scene.render(cam, cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    diff = np.abs(screen.accum - ref_accum).max(axis=2)
+    assert np.array_equal(screen.accum, ref_accum), "%d of %d pixels differ, max |d| = %g" % (
+        int((diff > 0).sum()), diff.size, diff.max())
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+    # north-star metric, for the record: per-pixel L2 on post-gamma [0,1] values
+    assert float(np.sqrt(((screen.rgb8.astype(np.float64) - ref_rgb8) ** 2).sum(axis=2)).max()) / 255.0 < 1e-4
+
+
+def test_gpu_equals_literal_oracle_book1(rtsr, orc):
+    """GPU vs O1 (the literal object-graph restatement with the reference's own BVH rule)."""
+    b, world, cam, cfg, flat = _setup(rtsr, 100, 120, 1.5, 6, {})
+    h = rtsr.image_height(cfg)
+    screen = flat.upload().render(cam, cfg)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=16)
+    assert np.array_equal(screen.accum, a1)
+    assert np.array_equal(screen.rgb8, r1)
+
+
+def test_scheduling_independence(rtsr, monkeypatch):
+    """Persistent/regenerating kernel vs the plain grid-stride kernel, one pass vs many passes."""
+    b, world, cam, cfg, flat = _setup(rtsr, 13, 128, 16.0 / 9.0, 16, {})
+    base = flat.upload().render(cam, cfg)
+    monkeypatch.setenv("RTX_TRACE_KERNEL", "simple")
+    simple = flat.upload().render(cam, cfg)
+    monkeypatch.delenv("RTX_TRACE_KERNEL")
+    assert np.array_equal(base.accum, simple.accum)
+    cfg2 = rtsr.RtxConfig.from_buffer_copy(cfg)
+    cfg2.sample_buffer_bytes = 128 * 72 * 24 * 3  # 3 samples per pass -> 6 passes
+    multi = flat.upload().render(cam, cfg2)
+    assert np.array_equal(base.accum, multi.accum)
+
+
+def test_device_arithmetic_matches_host(rtsr, orc):
+    rng = np.random.default_rng(5)
+    n = 200000
+    x = np.concatenate([rng.uniform(-1, 1, n), rng.uniform(-100, 100, n), rng.uniform(-6e4, 6e4, n)])
+    for fn in ("sin", "cos", "tan"):
+        assert np.array_equal(rtsr.device_math(fn, x), orc.rt_math(fn, x)), fn
+    u = np.concatenate([rng.uniform(0, 1, n), rng.uniform(0, 1e-9, n), [0.0, 1.0, 2.0 ** -53]])
+    assert np.array_equal(rtsr.device_math("log", u), orc.rt_math("log", u))
+    a = np.concatenate([rng.uniform(-1, 1, n), [1.0, -1.0, 0.0, 1.0000000001]])
+    assert np.array_equal(rtsr.device_math("acos", a), orc.rt_math("acos", a), equal_nan=True)
+    yy, xx = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    assert np.array_equal(rtsr.device_math("atan2", yy, xx), orc.rt_math("atan2", yy, xx))
+    p = np.abs(rng.normal(0, 1e3, n)) ** rng.uniform(0.1, 3, n)
+    assert np.array_equal(rtsr.device_math("sqrt", p), np.sqrt(p))
+    q = rng.normal(0, 10, n)
+    d = rng.normal(0, 10, n)
+    assert np.array_equal(rtsr.device_math("div", q, d), q / d)
+    assert np.array_equal(rtsr.device_math("muladd", q, d), q * d + q)  # no FMA contraction
+    assert np.array_equal(rtsr.device_math("floor", q), np.floor(q))
+
+
+def test_device_stream_matches_host(rtsr, orc):
+    import ctypes as C
+    for seed, pixel, sample in [(1, 0, 0), (7, 123456, 499), (2 ** 40 + 5, 2 ** 33 + 1, 2 ** 31)]:
+        host = np.empty(64)
+        orc.load().oracle_sample_stream(seed, pixel, sample, 64, host.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(rtsr.device_stream(seed, pixel, sample, 64), host)
