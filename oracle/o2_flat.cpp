@@ -110,6 +110,88 @@ int oracle_o2_sample(const void* flat, const OracleCamera* cam, const OracleConf
   return 0;
 }
 
+// ---- probes into the product's shared core (same KATs as the O1 probes) ---------------------
+void oracle_core_vec3_ops(const double a[3], const double b[3], double t, double out[24]) {
+  rt::Vec3 A = rt::v3(a[0], a[1], a[2]), B = rt::v3(b[0], b[1], b[2]);
+  int k = 0;
+  auto put = [&](rt::Vec3 v) { out[k++] = v.x; out[k++] = v.y; out[k++] = v.z; };
+  put(A + B); put(A - B); put(A * B); put(A * t); put(A / t); put(-A); put(rt::cross(A, B));
+  out[k++] = rt::dot(A, B); out[k++] = rt::length_squared(A); out[k++] = rt::length(A);
+}
+void oracle_core_tone_map(const double sum[3], uint32_t spp, int32_t out[3]) {
+  rt::tone_map(rt::v3(sum[0], sum[1], sum[2]), spp, out);
+}
+void oracle_core_sphere_uv(const double p[3], double uv[2]) { rt::get_sphere_uv(rt::v3(p[0], p[1], p[2]), &uv[0], &uv[1]); }
+double oracle_core_reflectance(double cosine, double ref_idx) { return rt::reflectance(cosine, ref_idx); }
+void oracle_core_refract(const double uv[3], const double n[3], double ratio, double out[3]) {
+  rt::Vec3 r = rt::refract(rt::v3(uv[0], uv[1], uv[2]), rt::v3(n[0], n[1], n[2]), ratio);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void oracle_core_reflect(const double v[3], const double n[3], double out[3]) {
+  rt::Vec3 r = rt::reflect(rt::v3(v[0], v[1], v[2]), rt::v3(n[0], n[1], n[2]));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+int oracle_core_aabb_hit(const double mn[3], const double mx[3], const double o[3], const double d[3], double t_min, double t_max) {
+  rt::Vec3 inv = rt::v3(1.0 / d[0], 1.0 / d[1], 1.0 / d[2]);
+  return rt::aabb_hit(mn, mx, rt::v3(o[0], o[1], o[2]), inv, t_min, t_max) ? 1 : 0;
+}
+// world_hit over a flattened scene with one ray: out = {t, p.xyz, n.xyz, u, v, front_face}
+int oracle_core_world_hit(const void* flat, const double o[3], const double d[3], double time, double t_min,
+                          double t_max, uint64_t rng_seed, double out[10]) {
+  if (!flat) return -1;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  const rt::SceneView sv = fs.view();
+  rt::LocalStack<128> stack;
+  stack.n = 0;
+  rt::Rng rng = rt::rng_for_sample(rng_seed, 0, 0);
+  rt::HitRecord rec;
+  rt::Ray r = rt::make_ray(rt::v3(o[0], o[1], o[2]), rt::v3(d[0], d[1], d[2]), time);
+  if (!rt::world_hit<rt::F_ALL, false>(sv, r, t_min, t_max, &rec, rng, stack, nullptr)) return 0;
+  out[0] = rec.t; out[1] = rec.p.x; out[2] = rec.p.y; out[3] = rec.p.z;
+  out[4] = rec.normal.x; out[5] = rec.normal.y; out[6] = rec.normal.z;
+  out[7] = rec.u; out[8] = rec.v; out[9] = rec.front_face ? 1.0 : 0.0;
+  return 1;
+}
+// Structural audit of a flattened scene (used by tests/test_host_logic.py): checks that every BVH
+// node box encloses its subtree's primitive boxes and every primitive sits in exactly one leaf.
+// Returns 0 when consistent, else a positive error code.
+static int audit_node(const rtx::FlatScene& fs, const rt::FlatEntry& e, int32_t child, const double* mn, const double* mx,
+                      std::vector<int>& seen, int depth, int* max_depth) {
+  if (depth > *max_depth) *max_depth = depth;
+  if (rt::node_child_is_leaf(child)) {
+    uint32_t f = rt::leaf_first(child), k = rt::leaf_count(child);
+    if (f + k > (uint32_t)e.c) return 2;
+    for (uint32_t i = 0; i < k; ++i) seen[f + i]++;
+    return 0;
+  }
+  if (child < 0 || (size_t)child >= fs.nodes.size()) return 3;
+  const rt::FlatNode& n = fs.nodes[child];
+  for (int c = 0; c < 2; ++c) {
+    for (int a = 0; a < 3; ++a)
+      if (mn && (n.bmin[c][a] < mn[a] || n.bmax[c][a] > mx[a])) return 4;
+    int rc = audit_node(fs, e, n.child[c], n.bmin[c], n.bmax[c], seen, depth + 1, max_depth);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int oracle_audit_flat(const void* flat, int32_t* max_depth_out) {
+  if (!flat) return -1;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  int max_depth = 0;
+  for (const rt::FlatEntry& e : fs.entries) {
+    if (e.kind != rt::ENTRY_BVH) continue;
+    std::vector<int> seen((size_t)e.c, 0);
+    int d = 0;
+    int rc = audit_node(fs, e, e.a, nullptr, nullptr, seen, 1, &d);
+    if (rc) return rc;
+    for (int v : seen)
+      if (v != 1) return 5;
+    if (d > max_depth) max_depth = d;
+  }
+  if (max_depth_out) *max_depth_out = max_depth;
+  return max_depth <= fs.max_stack + 1 ? 0 : 6;
+}
+
 void oracle_philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1) { rt::philox4x32_10(ctr, k0, k1); }
 uint64_t oracle_splitmix64_next(uint64_t* state) {
   rt::HostRng h{*state};

@@ -54,6 +54,19 @@ int oracle_o1_aabb_hit(const double mn[3], const double mx[3], const double o[3]
 int oracle_o1_hit(const void* graph, int32_t handle, const double o[3], const double d[3], double time,
                   double t_min, double t_max, uint64_t rng_seed, double out[10]);
 
+/* The same probes into the product's shared core (ray-tracing-series-rust_amd/csrc/core). */
+void oracle_core_vec3_ops(const double a[3], const double b[3], double t, double out[24]);
+void oracle_core_tone_map(const double sum[3], uint32_t spp, int32_t out[3]);
+void oracle_core_sphere_uv(const double p[3], double uv[2]);
+double oracle_core_reflectance(double cosine, double ref_idx);
+void oracle_core_refract(const double uv[3], const double n[3], double ratio, double out[3]);
+void oracle_core_reflect(const double v[3], const double n[3], double out[3]);
+int oracle_core_aabb_hit(const double mn[3], const double mx[3], const double o[3], const double d[3],
+                         double t_min, double t_max);
+int oracle_core_world_hit(const void* flat, const double o[3], const double d[3], double time, double t_min,
+                          double t_max, uint64_t rng_seed, double out[10]);
+int oracle_audit_flat(const void* flat, int32_t* max_depth_out);
+
 /* Shared-core probes (product headers compiled for the host): RNG and rt_math. */
 void oracle_philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1);
 uint64_t oracle_splitmix64_next(uint64_t* state);

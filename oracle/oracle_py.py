@@ -62,6 +62,25 @@ def load():
     lib.oracle_o1_aabb_hit.argtypes = [_D, _D, _D, _D, C.c_double, C.c_double]
     lib.oracle_o1_hit.restype = C.c_int
     lib.oracle_o1_hit.argtypes = [C.c_void_p, C.c_int32, _D, _D, C.c_double, C.c_double, C.c_double, C.c_uint64, _D]
+    for side in ("o1", "core"):
+        getattr(lib, "oracle_%s_vec3_ops" % side).restype = None
+        getattr(lib, "oracle_%s_vec3_ops" % side).argtypes = [_D, _D, C.c_double, _D]
+        getattr(lib, "oracle_%s_tone_map" % side).restype = None
+        getattr(lib, "oracle_%s_tone_map" % side).argtypes = [_D, C.c_uint32, C.POINTER(C.c_int32)]
+        getattr(lib, "oracle_%s_sphere_uv" % side).restype = None
+        getattr(lib, "oracle_%s_sphere_uv" % side).argtypes = [_D, _D]
+        getattr(lib, "oracle_%s_reflectance" % side).restype = C.c_double
+        getattr(lib, "oracle_%s_reflectance" % side).argtypes = [C.c_double, C.c_double]
+        getattr(lib, "oracle_%s_refract" % side).restype = None
+        getattr(lib, "oracle_%s_refract" % side).argtypes = [_D, _D, C.c_double, _D]
+        getattr(lib, "oracle_%s_reflect" % side).restype = None
+        getattr(lib, "oracle_%s_reflect" % side).argtypes = [_D, _D, _D]
+        getattr(lib, "oracle_%s_aabb_hit" % side).restype = C.c_int
+        getattr(lib, "oracle_%s_aabb_hit" % side).argtypes = [_D, _D, _D, _D, C.c_double, C.c_double]
+    lib.oracle_core_world_hit.restype = C.c_int
+    lib.oracle_core_world_hit.argtypes = [C.c_void_p, _D, _D, C.c_double, C.c_double, C.c_double, C.c_uint64, _D]
+    lib.oracle_audit_flat.restype = C.c_int
+    lib.oracle_audit_flat.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.oracle_philox4x32_10.restype = None
     lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
     lib.oracle_splitmix64_next.restype = C.c_uint64
@@ -149,3 +168,69 @@ def rt_math(fn, x, y=None):
     out = np.empty_like(x)
     lib.oracle_rt_math(names[fn], x.ctypes.data_as(_D), y.ctypes.data_as(_D), x.size, out.ctypes.data_as(_D))
     return out
+
+
+# ---- thin probe wrappers used by the known-answer tests (side = "o1" literal restatement, "core" product core)
+def vec3_ops(side, a, b, t):
+    out = (C.c_double * 24)()
+    getattr(load(), "oracle_%s_vec3_ops" % side)(_d3(a), _d3(b), float(t), out)
+    o = list(out)
+    names = ["add", "sub", "mul", "mul_t", "div_t", "neg", "cross"]
+    res = {n: tuple(o[3 * i:3 * i + 3]) for i, n in enumerate(names)}
+    res["dot"], res["length_squared"], res["length"] = o[21], o[22], o[23]
+    return res
+
+
+def tone_map(side, s, spp):
+    out = (C.c_int32 * 3)()
+    getattr(load(), "oracle_%s_tone_map" % side)(_d3(s), spp, out)
+    return tuple(out)
+
+
+def sphere_uv(side, p):
+    out = (C.c_double * 2)()
+    getattr(load(), "oracle_%s_sphere_uv" % side)(_d3(p), out)
+    return out[0], out[1]
+
+
+def reflectance(side, cosine, ref_idx):
+    return getattr(load(), "oracle_%s_reflectance" % side)(cosine, ref_idx)
+
+
+def refract(side, uv, n, ratio):
+    out = (C.c_double * 3)()
+    getattr(load(), "oracle_%s_refract" % side)(_d3(uv), _d3(n), ratio, out)
+    return tuple(out)
+
+
+def reflect(side, v, n):
+    out = (C.c_double * 3)()
+    getattr(load(), "oracle_%s_reflect" % side)(_d3(v), _d3(n), out)
+    return tuple(out)
+
+
+def aabb_hit(side, mn, mx, o, d, t_min, t_max):
+    return bool(getattr(load(), "oracle_%s_aabb_hit" % side)(_d3(mn), _d3(mx), _d3(o), _d3(d), t_min, t_max))
+
+
+def _rec(rc, out):
+    if rc <= 0:
+        return None
+    o = list(out)
+    return {"t": o[0], "p": tuple(o[1:4]), "normal": tuple(o[4:7]), "u": o[7], "v": o[8], "front_face": bool(o[9])}
+
+
+def o1_hit(graph_ptr, handle, o, d, time=0.0, t_min=0.001, t_max=float("inf"), rng_seed=1):
+    out = (C.c_double * 10)()
+    return _rec(load().oracle_o1_hit(graph_ptr, handle, _d3(o), _d3(d), time, t_min, t_max, rng_seed, out), out)
+
+
+def core_world_hit(flat_arrays_ptr, o, d, time=0.0, t_min=0.001, t_max=float("inf"), rng_seed=1):
+    out = (C.c_double * 10)()
+    return _rec(load().oracle_core_world_hit(flat_arrays_ptr, _d3(o), _d3(d), time, t_min, t_max, rng_seed, out), out)
+
+
+def audit_flat(flat_arrays_ptr):
+    depth = C.c_int32(0)
+    rc = load().oracle_audit_flat(flat_arrays_ptr, C.byref(depth))
+    return rc, depth.value

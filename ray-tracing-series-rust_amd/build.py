@@ -1,7 +1,6 @@
-"""Build the HIP shared library (and, for tests, the CPU oracle) in-tree.
+"""Build the HIP shared library in-tree.
 
     python ray-tracing-series-rust_amd/build.py            # product: lib/librtx_hip.so
-    python ray-tracing-series-rust_amd/build.py --oracle   # + oracle/_build/liboracle.so
 
 hipcc cross-compiles gfx950 code objects without a GPU.  `-ffp-contract=off` is part of the
 parity contract (the reference is Rust: no FMA contraction), not a tuning knob.
@@ -16,8 +15,6 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librtx_hip.so")
 APP_PATH = os.path.join(LIB_DIR, "rtx_render")
-ORACLE_DIR = os.path.join(REPO_DIR, "oracle")
-ORACLE_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 HIP_SOURCES = [
     "csrc/hip/render.hip",
@@ -82,22 +79,7 @@ def build_app(force=False, verbose=True):
     return APP_PATH
 
 
-def build_oracle(force=False, verbose=True):
-    """Test infrastructure only (oracle/): never loaded by the product."""
-    deps = [ORACLE_DIR + "/o1_literal.cpp", ORACLE_DIR + "/o2_flat.cpp", ORACLE_DIR + "/oracle_abi.h",
-            os.path.join(PKG_DIR, "csrc", "core"), os.path.join(PKG_DIR, "csrc", "host")]
-    if not force and not needs_build(ORACLE_PATH, deps):
-        return ORACLE_PATH
-    cmd = ["make", "-C", ORACLE_DIR] + (["-B"] if force else [])
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return ORACLE_PATH
-
-
 if __name__ == "__main__":
     force = "--force" in sys.argv
     build_library(force=force)
     build_app(force=force)
-    if "--oracle" in sys.argv:
-        build_oracle(force=force)

@@ -1,0 +1,122 @@
+"""O1 (literal object-graph restatement, reference BVH rule) vs O2 (product core over the product's
+flattened arrays and SAH BVH), on the CPU.  Equality here means the flattener, the BVH builder and the
+iterative traversal reproduce the reference's object-graph semantics bit for bit."""
+import numpy as np
+import pytest
+
+# (name, scene id, width, image aspect, spp, options)
+SCENES = [
+    ("checkered", 0, 48, 16 / 9, 4, {}),
+    ("two_perlin", 1, 48, 16 / 9, 4, {}),
+    ("earth_image_texture", 2, 48, 16 / 9, 4, {}),
+    ("simple_light", 3, 48, 16 / 9, 4, {}),
+    ("cornell_box_xform", 4, 40, 1.0, 4, {}),
+    ("cornell_smoke_media", 5, 40, 1.0, 4, {}),
+    ("book2_final", 6, 48, 1.0, 4, {}),
+    ("moving_test", 7, 48, 16 / 9, 4, {}),
+    ("nested_lists", 9, 48, 16 / 9, 4, {}),
+    ("triangle_test", 10, 48, 16 / 9, 4, {}),
+    ("dragon_mesh_8k", 11, 64, 16 / 9, 2, {"mesh_triangles": 8000}),
+    ("triangular_prism", 12, 40, 1.0, 4, {}),
+    ("book1_head", 13, 64, 16 / 9, 4, {}),
+    ("book1_canonical", 100, 64, 1.5, 4, {}),
+    ("empty_world", 101, 16, 16 / 9, 2, {}),
+]
+
+
+def _scene(rtsr, sid, width, aspect, spp, opts, seed=5, **cfgkw):
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(sid, **opts)
+    cfg = rtsr.Config.new(aspect, width, spp, 50, 4, seed=seed, background=bg, **cfgkw)
+    return b, world, cam, cfg, rtsr.image_height(cfg)
+
+
+@pytest.mark.parametrize("name,sid,width,aspect,spp,opts", SCENES, ids=[s[0] for s in SCENES])
+def test_flat_path_equals_literal_path(rtsr, orc, name, sid, width, aspect, spp, opts):
+    b, world, cam, cfg, h = _scene(rtsr, sid, width, aspect, spp, opts)
+    flat = b.flatten(world)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8)
+    a2, r2 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+    assert np.isfinite(a1).all()
+    assert np.array_equal(a1, a2), "%d pixels differ" % int((np.abs(a1 - a2).max(axis=2) > 0).sum())
+    assert np.array_equal(r1, r2)
+
+
+def test_bvh_topology_does_not_matter(rtsr, orc):
+    """Different reference-BVH axis streams (O1) and different SAH leaf sizes (O2): same image."""
+    b, world, cam, cfg, h = _scene(rtsr, 100, 64, 1.5, 4, {})
+    ref, _ = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8, bvh_seed=1)
+    other, _ = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8, bvh_seed=99)
+    assert np.array_equal(ref, other)
+    for leaf in (1, 2, 4, 8):
+        flat = b.flatten(world, max_leaf=leaf)
+        a2, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+        assert np.array_equal(ref, a2), "max_leaf=%d" % leaf
+
+
+def test_thread_count_and_seed(rtsr, orc):
+    b, world, cam, cfg, h = _scene(rtsr, 13, 48, 16 / 9, 3, {})
+    flat = b.flatten(world)
+    one, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=1)
+    many, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=7)
+    assert np.array_equal(one, many)                       # scheduling cannot change a sample
+    b2, world2, cam2, cfg2, _ = _scene(rtsr, 13, 48, 16 / 9, 3, {}, seed=6)
+    flat2 = b2.flatten(world2)
+    other, _ = orc.o2_render(flat2.arrays_ptr(), cam2, cfg2, h, threads=7)
+    assert not np.array_equal(one, other)                  # the render seed does
+
+
+def test_row_shards_tile_the_image(rtsr, orc):
+    """Shards {j : (j / B) % N == r} rendered separately reassemble the unsharded image exactly."""
+    b, world, cam, cfg, h = _scene(rtsr, 100, 40, 1.5, 2, {})
+    flat = b.flatten(world)
+    full, full8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+    for n, block in [(2, 1), (3, 1), (8, 1), (2, 4), (5, 3)]:
+        out = np.zeros_like(full)
+        for r in range(n):
+            part, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=(r, n, block), threads=4)
+            rows = [j for j in range(h) if (j // block) % n == r]
+            assert part.shape[0] == len(rows) == rtsr.shard_rows(cfg, (r, n, block))
+            out[rows] = part
+        assert np.array_equal(out, full), (n, block)
+
+
+def test_row_chunk_compat_quirk(rtsr, orc):
+    """world.rs:1198-1202: with `threads` bands of floor(h/threads) rows the remainder rows stay black."""
+    b, world, cam, cfg, h = _scene(rtsr, 100, 40, 1.5, 2, {}, row_chunk_compat=True)
+    cfg.threads = 4  # h = 26 -> 4 bands of 6 rows, rows 24..25 never rendered
+    flat = b.flatten(world)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h)
+    a2, r2 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h)
+    assert h == 26 and (a1[24:] == 0).all() and (r1[24:] == 0).all() and a1[:24].min() > 0
+    assert np.array_equal(a1, a2) and np.array_equal(r1, r2)
+
+
+def test_depth_exhaustion_and_background(rtsr, orc):
+    """world.rs:64-67: depth is decremented first; an exhausted path contributes nothing (no background)."""
+    b = rtsr.Builder(1)
+    inside = b.sphere((0, 0, 0), 100.0, b.metal((1, 1, 1), 0.0))  # camera inside a mirror ball: never escapes
+    cam = rtsr.Camera.new((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, 1.0, 0.0, 1.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.0, 8, 2, 7, 1, background=(0.7, 0.8, 1.0))
+    a1, _ = orc.o1_render(b.graph_ptr(), inside, cam, cfg, 8)
+    flat_inside = b.flatten(inside)
+    a2, _ = orc.o2_render(flat_inside.arrays_ptr(), cam, cfg, 8)
+    assert (a1 == 0).all() and (a2 == 0).all()
+    empty = b.hittable_list()
+    flat_empty = b.flatten(empty)
+    a1, _ = orc.o1_render(b.graph_ptr(), empty, cam, cfg, 8)
+    a2, _ = orc.o2_render(flat_empty.arrays_ptr(), cam, cfg, 8)
+    assert np.array_equal(a1, a2) and np.allclose(a1, np.array([0.7, 0.8, 1.0]) * 2)
+
+
+def test_statistical_agreement_between_scene_seeds(rtsr, orc):
+    """Different scene seeds give different sphere layouts but the same kind of image (sanity of the generator)."""
+    means = []
+    for seed in (1, 2):
+        b = rtsr.Builder(seed)
+        world, cam, bg = b.get_world_cam(100)
+        cfg = rtsr.Config.new(1.5, 48, 4, 50, 4, background=bg)
+        flat = b.flatten(world)
+        a, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, 32, threads=8)
+        means.append(a.mean() / 4)
+    assert means[0] != means[1] and abs(means[0] - means[1]) < 0.1
