@@ -1,0 +1,65 @@
+// Conservative single-precision box culling for BVH walks.
+//
+// The reference decides every hit with f64 primitive tests (hit.rs) and uses Aabb::hit
+// (aabb.rs:23-61) only to skip subtrees.  Skipping is an optimisation: if a box test never says
+// "miss" for a box the ray really enters, the set of primitive tests that can win is unchanged
+// and so is the closest hit (with its tie rule).  This header provides such a test in f32:
+//
+//   * child boxes are rounded outward to f32 on the host (lo down, hi up);
+//   * the ray is rounded to f32 once per bounce: o32 = fl(o), i32 = fl(1/d), oi = fl(o32*i32);
+//   * per axis t = fma(plane, i32, -oi); the slab interval is [min, max] of the two planes;
+//   * first-order error of each t against the real-arithmetic value:
+//         |t - T| <= 2^-24 * (2|t| + 4|oi|)          (rounding of o, 1/d, the product and the fma)
+//     so the interval is widened by |t| * 2^-22 + E with E = 2^-21 * max_axis |oi|.  Because
+//     f(t) = t - |t| eps is monotone the widening is applied once, after the max / min over axes;
+//   * t_min is rounded down, the running closest distance is rounded up;
+//   * a box passes unless the widened interval is provably empty (NaNs pass).
+// A zero direction component gives i32 = inf and NaN/inf slab values; fminf/fmaxf ignore NaN so
+// that axis simply stops culling (still conservative).  Host and device need not agree bit for bit
+// here -- any conservative answer gives the same final hit -- so FMA use is fine.
+#pragma once
+#include "flat_types.hpp"
+
+namespace rt {
+
+struct Ray32 {
+  float ix, iy, iz;     // fl(1/d)
+  float oix, oiy, oiz;  // fl(o32 * i32)
+  float err;            // E = 2^-21 * max |oi| over axes with finite slope
+  float t_min;          // rounded down
+};
+
+RT_HD float cull_round_up(double x) {  // smallest-effort f32 >= x for x >= 0 (inf stays inf)
+  return (float)x * 1.00000012f;
+}
+
+RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
+  Ray32 q;
+  float ox = (float)r.origin.x, oy = (float)r.origin.y, oz = (float)r.origin.z;
+  q.ix = (float)(1.0 / r.direction.x);
+  q.iy = (float)(1.0 / r.direction.y);
+  q.iz = (float)(1.0 / r.direction.z);
+  q.oix = ox * q.ix; q.oiy = oy * q.iy; q.oiz = oz * q.iz;
+  float ax = __builtin_fabsf(q.ix) < 1e30f ? __builtin_fabsf(q.oix) : 0.0f;
+  float ay = __builtin_fabsf(q.iy) < 1e30f ? __builtin_fabsf(q.oiy) : 0.0f;
+  float az = __builtin_fabsf(q.iz) < 1e30f ? __builtin_fabsf(q.oiz) : 0.0f;
+  q.err = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az)) * 0x1.0p-21f;
+  q.t_min = (float)t_min * 0.99999988f;
+  return q;
+}
+
+// true unless the ray provably misses the box within (t_min, t_max32]
+RT_HD bool cull32_may_hit(const float* lo, const float* hi, const Ray32& q, float t_max32) {
+  float ax = __builtin_fmaf(lo[0], q.ix, -q.oix), bx = __builtin_fmaf(hi[0], q.ix, -q.oix);
+  float ay = __builtin_fmaf(lo[1], q.iy, -q.oiy), by = __builtin_fmaf(hi[1], q.iy, -q.oiy);
+  float az = __builtin_fmaf(lo[2], q.iz, -q.oiz), bz = __builtin_fmaf(hi[2], q.iz, -q.oiz);
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                             __builtin_fmaxf(__builtin_fminf(az, bz), q.t_min));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                             __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
+  tn = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-22f, tn) - q.err;
+  tf = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-22f, tf) + q.err;
+  return !(tn > tf);
+}
+
+}  // namespace rt

@@ -59,6 +59,16 @@ struct FlatNode {  // 112 B
   int32_t child[2];
   int32_t pad[2];
 };
+// The same tree with child boxes rounded OUTWARD to f32 (64 B per node): the culling structure of
+// the fast kernels.  Node i of `nodes32` mirrors node i of `nodes`.  See core/cull32.hpp for why
+// culling in f32 cannot change a result.
+struct FlatNode32 {  // 64 B
+  float lo[2][3];
+  float hi[2][3];
+  int32_t child[2];
+  int32_t axis;
+  int32_t pad;
+};
 RT_HD bool node_child_is_leaf(int32_t c) { return c < 0; }
 RT_HD uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
 RT_HD uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1u; }
@@ -139,6 +149,7 @@ struct SceneView {
   const FlatRect* rects;
   const FlatTriangle* triangles;
   const FlatNode* nodes;
+  const FlatNode32* nodes32;
   const PrimRef* refs;
   const FlatEntry* entries;
   const int32_t* top_level;  // entry indices, in HittableList order

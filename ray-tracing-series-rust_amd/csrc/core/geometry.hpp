@@ -12,9 +12,10 @@
 //   * HittableList / RectPrism become ordered groups, Translate/RotateY become
 //     op lists on an entry, ConstantMedium becomes an entry kind.
 // Closest-hit results are independent of the traversal order; exact ties inside
-// one BVH are resolved as "higher position in the list handed to
-// BvhNode::from_list wins", the order-independent form of the reference's
-// "later object / right child wins" (hit.rs:676-680, bvh.rs:105).
+// one BVH are resolved as "higher slot in the BVH's flattened primitive list
+// wins", an order-independent stand-in for the reference's "right child wins"
+// (bvh.rs:105), whose outcome depends on its random split axes.  Ordered lists
+// keep the reference's "later object wins" exactly (hit.rs:676-680).
 #pragma once
 #include "flat_types.hpp"
 #include "rng.hpp"
@@ -245,52 +246,66 @@ RT_HD void offer_prim(const SceneView& sv, PrimRef ref, uint32_t order, const Ra
   best->hit = true;
 }
 
-// Iterative closest-hit walk of one flattened BVH.  STACK provides
-// reset() / push(int32_t) / pop() / empty(); the device instantiates it over LDS.
-// Children are visited near-first along the node's split axis (pure ordering: the
-// closest hit does not depend on it).
+// One step of the iterative closest-hit walk of a flattened BVH: visit `*node` (test its two
+// child boxes near-first along the split axis, intersect leaf children, choose where to go next).
+// Returns false when the walk is complete.  STACK provides reset() / push(int32_t) / pop() /
+// empty(); the device instantiates it over LDS.  The visiting order is pure scheduling: the
+// closest hit does not depend on it.  Exposed as a step so the device can interleave the walks
+// of many rays per lane (hip/render.hip, k_trace_stream); bvh_closest below simply loops it.
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD bool bvh_step(const SceneView& sv, uint32_t first_ref, const Ray& r, Vec3 inv_d, uint32_t dir_neg,
+                    double t_min, int32_t* node, Closest* best, STACK& stack, TraceCounters* cnt) {
+  const FlatNode& n = sv.nodes[*node];
+  if (COUNT) cnt->box_tests += 2;
+  int first = (int)((dir_neg >> (uint32_t)n.pad[0]) & 1u);  // near child along the split axis
+  bool hf = aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best->t);
+  int32_t cf = n.child[first];
+  int32_t next = -1;
+  bool have_next = false;
+  if (hf) {
+    if (node_child_is_leaf(cf)) {
+      uint32_t f = leaf_first(cf), k = leaf_count(cf);
+      for (uint32_t i = 0; i < k; ++i)
+        offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
+    } else {
+      next = cf; have_next = true;
+    }
+  }
+  // the far box is tested after the near leaf may have shrunk best->t
+  bool hs = aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best->t);
+  int32_t cs = n.child[1 - first];
+  if (hs) {
+    if (node_child_is_leaf(cs)) {
+      uint32_t f = leaf_first(cs), k = leaf_count(cs);
+      for (uint32_t i = 0; i < k; ++i)
+        offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
+    } else if (have_next) {
+      stack.push(cs);
+    } else {
+      next = cs; have_next = true;
+    }
+  }
+  if (have_next) { *node = next; return true; }
+  if (stack.empty()) return false;
+  *node = stack.pop();
+  return true;
+}
+
+RT_HD Vec3 ray_inv_dir(const Ray& r) {  // aabb.rs:48: inv_d = 1.0 / direction, per axis
+  return v3(1.0 / r.direction.x, 1.0 / r.direction.y, 1.0 / r.direction.z);
+}
+RT_HD uint32_t ray_dir_neg(const Ray& r) {  // bit a set: the ray travels towards -a
+  return (r.direction.x < 0.0 ? 1u : 0u) | (r.direction.y < 0.0 ? 2u : 0u) | (r.direction.z < 0.0 ? 4u : 0u);
+}
+
 template <uint32_t F, bool COUNT, class STACK>
 RT_HD void bvh_closest(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r,
                        double t_min, Closest* best, STACK& stack, TraceCounters* cnt) {
-  Vec3 inv_d = v3(1.0 / r.direction.x, 1.0 / r.direction.y, 1.0 / r.direction.z);
+  Vec3 inv_d = ray_inv_dir(r);
+  uint32_t dir_neg = ray_dir_neg(r);
   stack.reset();
   int32_t node = root;
-  for (;;) {
-    const FlatNode& n = sv.nodes[node];
-    if (COUNT) cnt->box_tests += 2;
-    int32_t axis = n.pad[0];
-    double dir_a = axis == 0 ? r.direction.x : (axis == 1 ? r.direction.y : r.direction.z);
-    int first = dir_a < 0.0 ? 1 : 0;
-    bool hf = aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best->t);
-    int32_t cf = n.child[first];
-    int32_t next = -1;
-    bool have_next = false;
-    if (hf) {
-      if (node_child_is_leaf(cf)) {
-        uint32_t f = leaf_first(cf), k = leaf_count(cf);
-        for (uint32_t i = 0; i < k; ++i)
-          offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
-      } else {
-        next = cf; have_next = true;
-      }
-    }
-    // the far box is tested after the near leaf may have shrunk best->t
-    bool hs = aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best->t);
-    int32_t cs = n.child[1 - first];
-    if (hs) {
-      if (node_child_is_leaf(cs)) {
-        uint32_t f = leaf_first(cs), k = leaf_count(cs);
-        for (uint32_t i = 0; i < k; ++i)
-          offer_prim<F, COUNT>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, cnt);
-      } else if (have_next) {
-        stack.push(cs);
-      } else {
-        next = cs; have_next = true;
-      }
-    }
-    if (have_next) { node = next; continue; }
-    if (stack.empty()) break;
-    node = stack.pop();
+  while (bvh_step<F, COUNT>(sv, first_ref, r, inv_d, dir_neg, t_min, &node, best, stack, cnt)) {
   }
 }
 

@@ -33,15 +33,20 @@ RT_HD void path_begin(const RenderParams& rp, uint32_t i, uint32_t j, uint32_t s
   ps->depth = rp.max_depth;
 }
 
-// One iteration of ray_color's loop.  Returns true when the path has ended and
-// ps->output holds the sample's radiance.
-template <uint32_t F, bool COUNT, class STACK>
-RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps, STACK& stack,
-                     TraceCounters* cnt) {
-  ps->depth -= 1;                  // world.rs:64
-  if (ps->depth < 0) return true;  // world.rs:65-67: no background term on exhaustion
-  HitRecord rec;
-  if (!world_hit<F, COUNT>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt)) {
+// One iteration of ray_color's loop, in two halves around the world.hit() query so the device
+// can run the query as a resumable walk:
+//   path_bounce_begin   world.rs:64-67  depth -= 1; exhausted paths end with what they gathered
+//   path_bounce_end     world.rs:68-90  miss -> background; hit -> scatter (draws), emitted, update
+// Both return true when the path has ended and ps->output holds the sample's radiance.
+RT_HD bool path_bounce_begin(PathState* ps) {
+  ps->depth -= 1;
+  return ps->depth < 0;
+}
+
+template <uint32_t F, bool COUNT>
+RT_HD bool path_bounce_end(const SceneView& sv, const RenderParams& rp, PathState* ps, bool hit,
+                           const HitRecord& rec, TraceCounters* cnt) {
+  if (!hit) {
     ps->output += ps->product * rp.background;  // world.rs:86-89
     return true;
   }
@@ -56,6 +61,15 @@ RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps,
   ps->product *= attenuation;
   ps->ray = scattered;
   return false;
+}
+
+template <uint32_t F, bool COUNT, class STACK>
+RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps, STACK& stack,
+                     TraceCounters* cnt) {
+  if (path_bounce_begin(ps)) return true;
+  HitRecord rec;
+  bool hit = world_hit<F, COUNT>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt);
+  return path_bounce_end<F, COUNT>(sv, rp, ps, hit, rec, cnt);
 }
 
 // Whole sample on one thread (CPU checker; also the device's simplest kernel).

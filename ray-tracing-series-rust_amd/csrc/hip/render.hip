@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include "../../../include/rtx_abi.h"
+#include "../core/cull32.hpp"
 #include "../core/integrator.hpp"
 #include "../host/flat_scene.hpp"
 #include "abi_internal.hpp"
@@ -42,6 +43,15 @@ struct DeviceScene {
   int n_cu = 256;
   int blocks_per_cu[3] = {1, 1, 1};  // resident 256-thread blocks per CU for each preset's persistent kernel
   bool force_simple = false;          // RTX_TRACE_KERNEL=simple
+  bool force_persistent = false;      // RTX_TRACE_KERNEL=persistent
+  bool force_stream = false;          // RTX_TRACE_KERNEL=stream
+  bool force_vote = false;            // RTX_TRACE_KERNEL=vote
+  bool vote_diag = false;             // RTX_TRACE_KERNEL=vote_diag: occupancy counters on stderr (never timed)
+  unsigned long long* diag = nullptr;
+  int vote_blocks_per_cu[2] = {1, 1};
+  bool single_bvh = false;            // world == one BVH entry -> k_trace_stream applies
+  int stream_blocks_per_cu[2] = {1, 1};
+  uint32_t walk_threshold = 32;       // RTX_WALK_THRESHOLD
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -74,6 +84,7 @@ static void free_device_scene(DeviceScene* ds) {
   if (ds->accum) (void)hipFree(ds->accum);
   if (ds->counters) (void)hipFree(ds->counters);
   if (ds->work_counter) (void)hipFree(ds->work_counter);
+  if (ds->diag) (void)hipFree(ds->diag);
   for (int i = 0; i < 2; ++i)
     if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
   delete ds;
@@ -223,6 +234,292 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView 
       }
     }
   }
+}
+
+// Stage-synchronous persistent kernel for worlds that are ONE BVH (Book-1: world = BvhNode,
+// world.rs:162-166).  k_trace_persistent keeps every lane busy at BOUNCE granularity, but inside a
+// bounce the wave still walks the BVH until its slowest ray is done (measured: 31 % VALU lane
+// utilisation).  Here the walk itself is resumable (core/geometry.hpp bvh_step) and a lane is in
+// one of three stages:
+//     NEED   no path: wants a sample index          (regenerated with __ballot + mbcnt compaction)
+//     WALK   its ray is inside the BVH               (one bvh_step per inner iteration)
+//     SHADE  walk finished: wants finalize + scatter (path_bounce_end) -> WALK again or NEED
+// The wave alternates two phases: (1) ALL lanes that are not walking shade / regenerate together,
+// (2) node steps run while at least `walk_threshold` lanes are still walking (all remaining ones
+// once the queue is empty).  Lanes that finish a walk wait at most until the walking population
+// falls under the threshold, so both phases run with a well-filled wave instead of the whole wave
+// waiting for the longest walk of every bounce.  Which lane does what is invisible in the result.
+enum : int { STAGE_NEED = 0, STAGE_WALK = 1, STAGE_SHADE = 2 };
+template <uint32_t F>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stream(rt::SceneView sv, rt::RenderParams rp,
+                                                              ShardMap sm, uint32_t s_begin,
+                                                              uint32_t total, uint32_t npix,
+                                                              double* __restrict__ samples,
+                                                              unsigned int* work_counter,
+                                                              uint32_t walk_threshold) {
+  extern __shared__ int32_t lds_stack[];
+  LdsStack stack;
+  stack.base = lds_stack + threadIdx.x;
+  stack.n = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const rt::FlatEntry& bvh = sv.entries[sv.top_level[0]];
+  const int32_t root = bvh.a;
+  const uint32_t first_ref = (uint32_t)bvh.b;
+  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
+  bool queue_empty = false;               // wave-uniform
+  int stage = STAGE_NEED;
+  uint32_t g = 0;
+  rt::PathState ps;
+  rt::Closest best;
+  rt::Vec3 inv_d = rt::v3(0, 0, 0);
+  uint32_t dir_neg = 0;
+  int32_t node = -1;  // -1: the lane's ray has not begun its bounce yet (phase 1c), >= 0: mid-walk
+  best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
+  for (;;) {
+    // ---- phase 1a: shade the lanes whose walk has finished
+    if (stage == STAGE_SHADE) {
+      rt::HitRecord rec;
+      if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
+      if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
+        double* o = samples + 3 * (size_t)g;
+        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
+        stage = STAGE_NEED;
+      } else {
+        stage = STAGE_WALK;  // new ray: bounce begins below
+      }
+    }
+    // ---- phase 1b: regenerate (wave-cooperative; executed by the whole wave)
+    {
+      unsigned long long need_mask = __ballot(stage == STAGE_NEED);
+      if (need_mask != 0ull) {
+        if (chunk_pos >= chunk_end && !queue_empty) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base >= total) {
+            queue_empty = true;
+          } else {
+            chunk_pos = base;
+            chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
+          }
+        }
+        if (chunk_pos < chunk_end) {
+          uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+          uint32_t n_need = (uint32_t)__popcll(need_mask);
+          uint32_t avail = chunk_end - chunk_pos;
+          if (stage == STAGE_NEED && rank < avail) {
+            g = chunk_pos + rank;
+            uint32_t s_local = g / npix;
+            uint32_t lp = g - s_local * npix;
+            uint32_t i, j;
+            shard_pixel(sm, lp, &i, &j);
+            rt::path_begin(rp, i, j, s_begin + s_local, &ps);
+            stage = STAGE_WALK;  // node == -1 here: phase 1c begins the first bounce
+          }
+          chunk_pos += (n_need < avail) ? n_need : avail;
+        }
+      }
+    }
+    // ---- phase 1c: begin the bounce of every lane that has a new ray (world.rs:64-68)
+    if (stage == STAGE_WALK && node < 0) {
+      if (rt::path_bounce_begin(&ps)) {  // depth exhausted: the path ends with what it gathered
+        double* o = samples + 3 * (size_t)g;
+        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
+        stage = STAGE_NEED;
+      } else {
+        inv_d = rt::ray_inv_dir(ps.ray);
+        dir_neg = rt::ray_dir_neg(ps.ray);
+        best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
+        stack.reset();
+        node = root;
+      }
+    }
+    // ---- exit: nothing walking, nothing to shade, queue drained
+    unsigned long long walk_mask = __ballot(stage == STAGE_WALK);
+    if (walk_mask == 0ull) {
+      if (queue_empty && __ballot(stage != STAGE_NEED) == 0ull) break;
+      continue;  // lanes whose path ended in 1c: go regenerate
+    }
+    // ---- phase 2: node steps while enough lanes walk
+    const uint32_t threshold = queue_empty ? 1u : walk_threshold;
+    do {
+      if (stage == STAGE_WALK) {
+        if (!rt::bvh_step<F, false>(sv, first_ref, ps.ray, inv_d, dir_neg, 0.001, &node, &best, stack, nullptr)) {
+          stage = STAGE_SHADE;
+          node = -1;  // the next ray of this lane starts a new bounce
+        }
+      }
+      walk_mask = __ballot(stage == STAGE_WALK);
+    } while ((uint32_t)__popcll(walk_mask) >= threshold);
+  }
+}
+
+// ---- wave-synchronous BVH walk with deferred leaves --------------------------------------------
+// In bvh_step a leaf child is intersected inline, i.e. inside a branch only the lanes that reached
+// a leaf take, while the rest of the wave waits -- on every step.  Here a leaf is just another work
+// item: an item is a node (code >= 0) or a leaf (code < 0); a node step tests the node's two child
+// boxes and only QUEUES hit children (near one becomes the current item, far one goes on the LDS
+// stack), a leaf step intersects the leaf's primitives.  Each iteration the wave votes (__ballot)
+// and runs the kind of step most of its lanes are waiting for, so both bodies run well filled.
+// Visiting order differs from bvh_step; the closest hit (with its tie rule) does not.
+#define WALK_DONE 0x7fffffff
+template <uint32_t F>
+__device__ __forceinline__ void walk_node_step(const rt::SceneView& sv, const rt::Ray& r, rt::Vec3 inv_d,
+                                               uint32_t dir_neg, double t_min, double best_t,
+                                               int32_t* cur, LdsStack& stack) {
+  const rt::FlatNode& n = sv.nodes[*cur];
+  int first = (int)((dir_neg >> (uint32_t)n.pad[0]) & 1u);
+  bool hf = rt::aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best_t);
+  bool hs = rt::aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best_t);
+  int32_t cf = n.child[first], cs = n.child[1 - first];
+  if (hf) {
+    *cur = cf;
+    if (hs) stack.push(cs);
+  } else if (hs) {
+    *cur = cs;
+  } else {
+    *cur = stack.empty() ? WALK_DONE : stack.pop();
+  }
+}
+// Node step on the f32 culling tree (core/cull32.hpp): cheaper per step (2-cycle f32 issue, 64-B
+// node) and, being conservative, invisible in the result.
+__device__ __forceinline__ void walk_node_step32(const rt::SceneView& sv, const rt::Ray32& q, uint32_t dir_neg,
+                                                 float t_max32, int32_t* cur, LdsStack& stack) {
+  const rt::FlatNode32& n = sv.nodes32[*cur];
+  int first = (int)((dir_neg >> (uint32_t)n.axis) & 1u);
+  bool hf = rt::cull32_may_hit(n.lo[first], n.hi[first], q, t_max32);
+  bool hs = rt::cull32_may_hit(n.lo[1 - first], n.hi[1 - first], q, t_max32);
+  int32_t cf = n.child[first], cs = n.child[1 - first];
+  if (hf) {
+    *cur = cf;
+    if (hs) stack.push(cs);
+  } else if (hs) {
+    *cur = cs;
+  } else {
+    *cur = stack.empty() ? WALK_DONE : stack.pop();
+  }
+}
+template <uint32_t F>
+__device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t first_ref, const rt::Ray& r,
+                                               double t_min, rt::Closest* best, int32_t* cur, LdsStack& stack) {
+  uint32_t f = rt::leaf_first(*cur), k = rt::leaf_count(*cur);
+  for (uint32_t i = 0; i < k; ++i)
+    rt::offer_prim<F, false>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, nullptr);
+  *cur = stack.empty() ? WALK_DONE : stack.pop();
+}
+
+// k_trace_persistent with the deferred-leaf walk, for worlds that are one BVH.
+// DIAG: per-region occupancy counters (diag[2k] = times the wave executed region k, diag[2k+1] = lanes
+// active in it); regions: 0 outer iteration, 1 regenerate, 2 node step, 3 leaf step, 4 shade (hit lanes),
+// 5 shade (all walking lanes).  Diagnostic build only (RTX_TRACE_KERNEL=vote_diag); never timed.
+template <uint32_t F, bool DIAG>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
+                                                            ShardMap sm, uint32_t s_begin, uint32_t total,
+                                                            uint32_t npix, double* __restrict__ samples,
+                                                            unsigned int* work_counter,
+                                                            unsigned long long* diag) {
+  unsigned long long dg[12];
+  if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
+#define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
+  extern __shared__ int32_t lds_stack[];
+  LdsStack stack;
+  stack.base = lds_stack + threadIdx.x;
+  stack.n = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const rt::FlatEntry& bvh = sv.entries[sv.top_level[0]];
+  const int32_t root = bvh.a;
+  const uint32_t first_ref = (uint32_t)bvh.b;
+  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
+  bool queue_empty = false;               // wave-uniform
+  bool active = false;
+  uint32_t g = 0;
+  rt::PathState ps;
+  for (;;) {
+    unsigned long long need_mask = __ballot(!active);
+    if (need_mask != 0ull) {
+      if (chunk_pos >= chunk_end && !queue_empty) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total) {
+          queue_empty = true;
+        } else {
+          chunk_pos = base;
+          chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
+        }
+      }
+      if (chunk_pos < chunk_end) {
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+        uint32_t n_need = (uint32_t)__popcll(need_mask);
+        uint32_t avail = chunk_end - chunk_pos;
+        DIAG_ADD(1, __ballot(!active && rank < avail));
+        if (!active && rank < avail) {
+          g = chunk_pos + rank;
+          uint32_t s_local = g / npix;
+          uint32_t lp = g - s_local * npix;
+          uint32_t i, j;
+          shard_pixel(sm, lp, &i, &j);
+          rt::path_begin(rp, i, j, s_begin + s_local, &ps);
+          active = true;
+        }
+        chunk_pos += (n_need < avail) ? n_need : avail;
+      }
+    }
+    if (__ballot(active) == 0ull) break;
+    DIAG_ADD(0, __ballot(active));
+    // ---- one bounce for every active lane
+    bool walking = false;
+    if (active) {
+      if (rt::path_bounce_begin(&ps)) {
+        double* o = samples + 3 * (size_t)g;
+        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
+        active = false;
+      } else {
+        walking = true;
+      }
+    }
+    rt::Closest best;
+    best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
+    rt::Ray32 q = rt::make_ray32(ps.ray, 0.001);
+    uint32_t dir_neg = rt::ray_dir_neg(ps.ray);
+    float t_max32 = __builtin_huge_valf();
+    stack.reset();
+    int32_t cur = walking ? root : WALK_DONE;
+    for (;;) {
+      bool is_leaf = cur < 0;
+      bool is_node = !is_leaf && cur != WALK_DONE;
+      unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
+      if ((m_node | m_leaf) == 0ull) break;
+      if (__popcll(m_node) >= __popcll(m_leaf)) {
+        DIAG_ADD(2, m_node);
+        if (is_node) walk_node_step32(sv, q, dir_neg, t_max32, &cur, stack);
+      } else {
+        DIAG_ADD(3, m_leaf);
+        if (is_leaf) {
+          walk_leaf_step<F>(sv, first_ref, ps.ray, 0.001, &best, &cur, stack);
+          t_max32 = rt::cull_round_up(best.t);
+        }
+      }
+    }
+    DIAG_ADD(4, __ballot(walking && best.hit));
+    DIAG_ADD(5, __ballot(walking));
+    if (walking) {
+      rt::HitRecord rec;
+      if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
+      if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
+        double* o = samples + 3 * (size_t)g;
+        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
+        active = false;
+      }
+    }
+  }
+  if (DIAG) {
+    if (lane == 0)
+      for (int k = 0; k < 12; ++k) atomicAdd(&diag[k], dg[k]);
+  }
+#undef DIAG_ADD
 }
 
 // One lane per pixel; samples of the pass are added in ascending sample index.
@@ -402,11 +699,51 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_simple<FEAT, COUNT>), dim3(grid), dim3(TRACE_BLOCK),     \
                      lds_bytes, stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, \
                      ds->counters)
-        if (COUNT) { LAUNCH_SIMPLE(P_ALL); }
-        else if (preset == 0) { LAUNCH_SIMPLE(P_SPHERES); }
-        else if (preset == 1) { LAUNCH_SIMPLE(P_MESH); }
-        else { LAUNCH_SIMPLE(P_ALL); }
+        if constexpr (COUNT) { LAUNCH_SIMPLE(P_ALL); }
+        else {
+          if (preset == 0) { LAUNCH_SIMPLE(P_SPHERES); }
+          else if (preset == 1) { LAUNCH_SIMPLE(P_MESH); }
+          else { LAUNCH_SIMPLE(P_ALL); }
+        }
 #undef LAUNCH_SIMPLE
+      } else if (ds->single_bvh && preset < 2 && !ds->force_persistent && !ds->force_stream) {
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->vote_blocks_per_cu[preset];
+        uint32_t grid = (uint32_t)(want < resident ? want : resident);
+#define LAUNCH_VOTE(FEAT)                                                                             \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, \
+                     stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
+                     ds->work_counter, (unsigned long long*)nullptr)
+        if (ds->vote_diag && preset == 0) {
+          if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 12 * sizeof(unsigned long long)));
+          HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_SPHERES, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes,
+                             stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,
+                             ds->work_counter, ds->diag);
+          HIP_TRY(hipStreamSynchronize(stream));
+          unsigned long long h[12];
+          HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
+          const char* names[6] = {"outer", "regen", "node_step", "leaf_step", "shade_hit", "walking"};
+          for (int k = 0; k < 6; ++k)
+            fprintf(stderr, "[vote_diag] %-10s executions %llu lanes %llu mean lanes %.2f\n", names[k], h[2 * k], h[2 * k + 1],
+                    h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+        }
+        else if (preset == 0) { LAUNCH_VOTE(P_SPHERES); }
+        else { LAUNCH_VOTE(P_MESH); }
+#undef LAUNCH_VOTE
+      } else if (ds->single_bvh && preset < 2 && ds->force_stream) {
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->stream_blocks_per_cu[preset];
+        uint32_t grid = (uint32_t)(want < resident ? want : resident);
+#define LAUNCH_STREAM(FEAT)                                                                           \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_stream<FEAT>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes,  \
+                     stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
+                     ds->work_counter, ds->walk_threshold)
+        if (preset == 0) { LAUNCH_STREAM(P_SPHERES); }
+        else { LAUNCH_STREAM(P_MESH); }
+#undef LAUNCH_STREAM
       } else {
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -481,7 +818,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
   rtx_status st;
 #define UP(field, vec) if ((st = upload_array(ds, fs.vec, &v.field)) != RTX_OK) { free_device_scene(ds); return st; }
   UP(spheres, spheres) UP(moving_spheres, moving_spheres) UP(rects, rects) UP(triangles, triangles)
-  UP(nodes, nodes) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
+  UP(nodes, nodes) UP(nodes32, nodes32) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
   UP(materials, materials) UP(textures, textures) UP(perlins, perlins) UP(images, images) UP(texels, texels)
 #undef UP
   v.n_top_level = (int32_t)fs.top_level.size();
@@ -497,8 +834,19 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[0] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[1] = nb;
     const char* k = getenv("RTX_TRACE_KERNEL");
     ds->force_simple = (k && strcmp(k, "simple") == 0);
+    ds->force_persistent = (k && strcmp(k, "persistent") == 0);
+    ds->force_stream = (k && strcmp(k, "stream") == 0);
+    ds->vote_diag = (k && strcmp(k, "vote_diag") == 0);
+    ds->force_vote = ds->vote_diag || (k && strcmp(k, "vote") == 0);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[0] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[1] = nb;
+    ds->single_bvh = fs.top_level.size() == 1 && fs.entries[fs.top_level[0]].kind == rt::ENTRY_BVH;
+    const char* wt = getenv("RTX_WALK_THRESHOLD");
+    if (wt && atoi(wt) >= 1 && atoi(wt) <= 64) ds->walk_threshold = (uint32_t)atoi(wt);
   }
   *out = make_scene_handle(ds);
   return RTX_OK;

@@ -14,6 +14,7 @@ struct FlatScene {
   std::vector<rt::FlatRect> rects;
   std::vector<rt::FlatTriangle> triangles;
   std::vector<rt::FlatNode> nodes;
+  std::vector<rt::FlatNode32> nodes32;  // same tree, boxes rounded outward to f32 (core/cull32.hpp)
   std::vector<rt::PrimRef> refs;
   std::vector<rt::FlatEntry> entries;
   std::vector<int32_t> top_level;
@@ -35,6 +36,7 @@ struct FlatScene {
     v.rects = rects.data();
     v.triangles = triangles.data();
     v.nodes = nodes.data();
+    v.nodes32 = nodes32.data();
     v.refs = refs.data();
     v.entries = entries.data();
     v.top_level = top_level.data();

@@ -23,7 +23,7 @@ using rt::Vec3;
 size_t FlatScene::total_bytes() const {
   return spheres.size() * sizeof(rt::FlatSphere) + moving_spheres.size() * sizeof(rt::FlatMovingSphere) +
          rects.size() * sizeof(rt::FlatRect) + triangles.size() * sizeof(rt::FlatTriangle) +
-         nodes.size() * sizeof(rt::FlatNode) + refs.size() * sizeof(rt::PrimRef) +
+         nodes.size() * sizeof(rt::FlatNode) + nodes32.size() * sizeof(rt::FlatNode32) + refs.size() * sizeof(rt::PrimRef) +
          entries.size() * sizeof(rt::FlatEntry) + top_level.size() * sizeof(int32_t) +
          materials.size() * sizeof(rt::FlatMaterial) + textures.size() * sizeof(rt::FlatTexture) +
          perlins.size() * sizeof(rt::FlatPerlin) + images.size() * sizeof(rt::FlatImage) +
@@ -324,6 +324,22 @@ struct Flattener {
       else if (t.kind == rt::TEX_IMAGE) f |= rt::F_IMAGE;
     }
     out.features = f;
+    // f32 culling copy of every node: lo rounded down, hi rounded up
+    out.nodes32.resize(out.nodes.size());
+    for (size_t i = 0; i < out.nodes.size(); ++i) {
+      const rt::FlatNode& n = out.nodes[i];
+      rt::FlatNode32& m = out.nodes32[i];
+      for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 3; ++a) {
+          float lo = (float)n.bmin[c][a];
+          if ((double)lo > n.bmin[c][a]) lo = std::nextafterf(lo, -INFINITY);
+          float hi = (float)n.bmax[c][a];
+          if ((double)hi < n.bmax[c][a]) hi = std::nextafterf(hi, INFINITY);
+          m.lo[c][a] = lo; m.hi[c][a] = hi;
+        }
+      m.child[0] = n.child[0]; m.child[1] = n.child[1];
+      m.axis = n.pad[0]; m.pad = 0;
+    }
     return true;
   }
 };
