@@ -140,21 +140,30 @@ RT_HD Color material_emitted(const SceneView& sv, const FlatMaterial& m, const H
 }
 
 // Material::scatter for all five materials.
+// Lambertian, Metal and Isotropic each begin by drawing one random_in_unit_sphere() sample
+// (hit.rs:1040 via random_unit_vector, hit.rs:1074, hit.rs:1007) and draw nothing else, so the
+// rejection loop is hoisted in front of the material switch: same draws in the same order, but the
+// loop exists once in the kernel and all three materials' lanes iterate it together.
 template <uint32_t F, bool COUNT>
 RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ray& r_in,
                             const HitRecord& rec, Rng& g, Ray* scattered, Color* attenuation,
                             TraceCounters* cnt) {
   if (COUNT) cnt->scatters++;
-  if ((F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN) {  // hit.rs:1039-1051
-    Vec3 scatter_direction = rec.normal + random_unit_vector(g);
+  const bool is_lambertian = (F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN;
+  const bool is_metal = (F & F_METAL) && m.kind == MAT_METAL;
+  const bool is_isotropic = (F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC;
+  Vec3 sphere_sample = v3(0, 0, 0);
+  if (is_lambertian || is_metal || is_isotropic) sphere_sample = random_in_unit_sphere(g);
+  if (is_lambertian) {  // hit.rs:1039-1051
+    Vec3 scatter_direction = rec.normal + unit(sphere_sample);  // random_unit_vector, vec3.rs:297-299
     if (near_zero(scatter_direction)) scatter_direction = rec.normal;
     *scattered = make_ray(rec.p, scatter_direction, r_in.time);
     *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
     return true;
   }
-  if ((F & F_METAL) && m.kind == MAT_METAL) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
+  if (is_metal) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
     Vec3 reflected = reflect(unit(r_in.direction), rec.normal);
-    Vec3 dir = reflected + m.param * random_in_unit_sphere(g);
+    Vec3 dir = reflected + m.param * sphere_sample;
     *scattered = make_ray(rec.p, dir, r_in.time);
     *attenuation = load_v3(m.albedo);
     return dot(dir, rec.normal) > 0.0;
@@ -174,9 +183,8 @@ RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ra
     *attenuation = v3(1, 1, 1);
     return true;
   }
-  if ((F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC) {  // hit.rs:1005-1010
-    Vec3 dir = random_in_unit_sphere(g);
-    *scattered = make_ray(rec.p, dir, r_in.time);
+  if (is_isotropic) {  // hit.rs:1005-1010
+    *scattered = make_ray(rec.p, sphere_sample, r_in.time);
     *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
     return true;
   }

@@ -51,7 +51,8 @@ struct DeviceScene {
   int vote_blocks_per_cu[2] = {1, 1};
   bool single_bvh = false;            // world == one BVH entry -> k_trace_stream applies
   int stream_blocks_per_cu[2] = {1, 1};
-  uint32_t walk_threshold = 32;       // RTX_WALK_THRESHOLD
+  uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
+  uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -414,11 +415,12 @@ __device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t
 // active in it); regions: 0 outer iteration, 1 regenerate, 2 node step, 3 leaf step, 4 shade (hit lanes),
 // 5 shade (all walking lanes).  Diagnostic build only (RTX_TRACE_KERNEL=vote_diag); never timed.
 template <uint32_t F, bool DIAG>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
+__global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
                                                             ShardMap sm, uint32_t s_begin, uint32_t total,
                                                             uint32_t npix, double* __restrict__ samples,
                                                             unsigned int* work_counter,
-                                                            unsigned long long* diag) {
+                                                            unsigned long long* diag, uint32_t leaf_weight,
+                                                            uint32_t walk_threshold) {
   unsigned long long dg[12];
   if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
 #define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
@@ -435,6 +437,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_vote(rt::SceneView sv, rt
   bool active = false;
   uint32_t g = 0;
   rt::PathState ps;
+  // walk state, kept across outer iterations so an unfinished walk can be carried over
+  bool midwalk = false;
+  rt::Ray32 q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t dir_neg = 0;
+  float t_max32 = 0.f;
+  int32_t cur = WALK_DONE;
+  rt::Closest best;
+  best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
   for (;;) {
     unsigned long long need_mask = __ballot(!active);
     if (need_mask != 0ull) {
@@ -469,30 +479,33 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_vote(rt::SceneView sv, rt
     }
     if (__ballot(active) == 0ull) break;
     DIAG_ADD(0, __ballot(active));
-    // ---- one bounce for every active lane
-    bool walking = false;
-    if (active) {
+    // ---- begin a bounce for every lane that is not in the middle of a carried-over walk
+    if (active && !midwalk) {
       if (rt::path_bounce_begin(&ps)) {
         double* o = samples + 3 * (size_t)g;
         o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
         active = false;
       } else {
-        walking = true;
+        q = rt::make_ray32(ps.ray, 0.001);
+        dir_neg = rt::ray_dir_neg(ps.ray);
+        t_max32 = __builtin_huge_valf();
+        best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
+        stack.reset();
+        cur = root;
+        midwalk = true;
       }
     }
-    rt::Closest best;
-    best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
-    rt::Ray32 q = rt::make_ray32(ps.ray, 0.001);
-    uint32_t dir_neg = rt::ray_dir_neg(ps.ray);
-    float t_max32 = __builtin_huge_valf();
-    stack.reset();
-    int32_t cur = walking ? root : WALK_DONE;
+    // ---- walk: cost-weighted node/leaf vote.  The loop stops as soon as fewer than `walk_threshold`
+    // lanes are still walking: the stragglers keep their walk state and continue next round, so the
+    // wave never waits for the longest walk of a bounce (all remaining ones once the queue is empty).
+    const uint32_t threshold = queue_empty ? 1u : walk_threshold;
     for (;;) {
-      bool is_leaf = cur < 0;
-      bool is_node = !is_leaf && cur != WALK_DONE;
+      bool walking = midwalk && cur != WALK_DONE;
+      bool is_leaf = walking && cur < 0;
+      bool is_node = walking && cur >= 0;
       unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
-      if ((m_node | m_leaf) == 0ull) break;
-      if (__popcll(m_node) >= __popcll(m_leaf)) {
+      if ((uint32_t)__popcll(m_node | m_leaf) < threshold) break;
+      if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
         DIAG_ADD(2, m_node);
         if (is_node) walk_node_step32(sv, q, dir_neg, t_max32, &cur, stack);
       } else {
@@ -503,9 +516,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_vote(rt::SceneView sv, rt
         }
       }
     }
-    DIAG_ADD(4, __ballot(walking && best.hit));
-    DIAG_ADD(5, __ballot(walking));
-    if (walking) {
+    // ---- shade the lanes whose walk is complete
+    const bool finished = midwalk && cur == WALK_DONE;
+    DIAG_ADD(4, __ballot(finished && best.hit));
+    DIAG_ADD(5, __ballot(finished));
+    if (finished) {
+      midwalk = false;
       rt::HitRecord rec;
       if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
       if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
@@ -714,13 +730,13 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
 #define LAUNCH_VOTE(FEAT)                                                                             \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
-                     ds->work_counter, (unsigned long long*)nullptr)
+                     ds->work_counter, (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 12 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_SPHERES, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes,
                              stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,
-                             ds->work_counter, ds->diag);
+                             ds->work_counter, ds->diag, ds->leaf_weight, ds->walk_threshold);
           HIP_TRY(hipStreamSynchronize(stream));
           unsigned long long h[12];
           HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
@@ -845,6 +861,8 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[1] = nb;
     ds->single_bvh = fs.top_level.size() == 1 && fs.entries[fs.top_level[0]].kind == rt::ENTRY_BVH;
+    const char* lw = getenv("RTX_LEAF_WEIGHT");
+    if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
     const char* wt = getenv("RTX_WALK_THRESHOLD");
     if (wt && atoi(wt) >= 1 && atoi(wt) <= 64) ds->walk_threshold = (uint32_t)atoi(wt);
   }
