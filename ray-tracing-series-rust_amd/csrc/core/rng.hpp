@@ -9,9 +9,11 @@
 //   stream state  = Philox4x32-10( counter = {pixel_lo, pixel_hi, sample, 0},
 //                                  key     = {seed_lo, seed_hi} )     (128 bits)
 //   k-th draw     = k-th output of xoroshiro128++ started from that state
-//   uniform f64   = (u64 >> 11) * 2^-53   in [0,1)   (53 high bits, as rand 0.8's
-//                                                      Standard f64 distribution)
-//   range(a,b)    = a + (b - a) * uniform
+//   gen::<f64>()      = (u64 >> 11) * 2^-53  in [0,1)   (53 high bits: rand 0.8's Standard
+//                                                        distribution for f64)
+//   gen_range(a..b)   = v12 * (b - a) + (a - (b - a)),  v12 = bits(0x3FF0.. | u64 >> 12) in [1,2)
+//                       (52 mantissa bits: rand 0.8's UniformFloat::sample_single, without its
+//                        redraw when rounding lands exactly on b)
 //
 // Philox (Salmon et al., SC'11) gives statistically independent streams for
 // every (pixel, sample) at one evaluation per path; xoroshiro128++ (Blackman &
@@ -78,8 +80,14 @@ RT_HD double u64_to_unit_f64(uint64_t x) {
 
 // rng.gen::<f64>()
 RT_HD double rng_f64(Rng& r) { return u64_to_unit_f64(rng_next_u64(r)); }
-// rng.gen_range(lo..hi) for f64
-RT_HD double rng_range(Rng& r, double lo, double hi) { return lo + (hi - lo) * rng_f64(r); }
+// rng.gen_range(lo..hi) for f64: the [1,2) mantissa construction of rand 0.8.5's
+// UniformFloat<f64>::sample_single -- value1_2 * scale + (low - scale).
+RT_HD double u64_to_f64_1_2(uint64_t x) { return bits_f64((x >> 12) | 0x3FF0000000000000ull); }
+RT_HD double rng_range(Rng& r, double lo, double hi) {
+  double scale = hi - lo;
+  double offset = lo - scale;
+  return u64_to_f64_1_2(rng_next_u64(r)) * scale + offset;
+}
 
 // SplitMix64: host-side generator for scene construction (random sphere
 // placement, box heights, Perlin tables, the oracle's reference-rule BVH axis).
@@ -93,7 +101,11 @@ RT_HD uint64_t host_rng_next_u64(HostRng& h) {
   return z ^ (z >> 31);
 }
 RT_HD double host_rng_f64(HostRng& h) { return u64_to_unit_f64(host_rng_next_u64(h)); }
-RT_HD double host_rng_range(HostRng& h, double lo, double hi) { return lo + (hi - lo) * host_rng_f64(h); }
+RT_HD double host_rng_range(HostRng& h, double lo, double hi) {
+  double scale = hi - lo;
+  double offset = lo - scale;
+  return u64_to_f64_1_2(host_rng_next_u64(h)) * scale + offset;
+}
 // gen_range(lo..hi) for integers, lo < hi.
 RT_HD uint64_t host_rng_below(HostRng& h, uint64_t n) { return host_rng_next_u64(h) % n; }
 
