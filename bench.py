@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (marks the run as non-headline)")
     ap.add_argument("--count-spp", type=int, default=32, help="spp of the instrumented counting run (same pixels and seeds)")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work (wall seconds) of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on a box with fewer GPUs than ranks (shards gathered through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true")
     args = ap.parse_args()
@@ -70,11 +71,16 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world_size, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU render path")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
+    torch.cuda.set_device(device_index)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
 
     rtsr = importlib.import_module("ray-tracing-series-rust_amd")
     sid, width, aspect, spp, depth, desc = WORKLOADS[args.workload]
@@ -92,8 +98,9 @@ def main():
     max_rows = max(rtsr.shard_rows(cfg, (r, world_size, 1)) for r in range(world_size))
     d_rgb8 = torch.zeros(max_rows * width * 3, dtype=torch.uint8, device="cuda")
     gather_list = None
+    host_stage = torch.empty(d_rgb8.numel(), dtype=torch.uint8) if (world_size > 1 and args.backend == "gloo") else None
     if world_size > 1 and rank == 0:
-        gather_list = [torch.empty_like(d_rgb8) for _ in range(world_size)]
+        gather_list = [torch.empty_like(host_stage if host_stage is not None else d_rgb8) for _ in range(world_size)]
     stream = torch.cuda.current_stream().cuda_stream
 
     trace_ms = []
@@ -103,7 +110,11 @@ def main():
         if record:
             trace_ms.append((stats.trace_ms, stats.trace_launches))
         if world_size > 1:
-            dist.gather(d_rgb8, gather_list=gather_list, dst=0)
+            if host_stage is not None:
+                host_stage.copy_(d_rgb8)  # gloo rehearsal path only
+                dist.gather(host_stage, gather_list=gather_list, dst=0)
+            else:
+                dist.gather(d_rgb8, gather_list=gather_list, dst=0)  # one RCCL gather per frame
 
     def fence():
         if world_size > 1:
@@ -171,13 +182,18 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py as orc
             ccfg = rtsr.RtxConfig.from_buffer_copy(cfg)
-            cpu_spp = max(1, min(spp, args.cpu_spp))
-            ccfg.samples_per_pixel = cpu_spp
             cores = os.cpu_count() or 1
             try:
                 cores = len(os.sched_getaffinity(0))
             except Exception:
                 pass
+            # calibrate on 1 spp, then size the sample to ~args.cpu_seconds of wall time (bounded by the full spp)
+            ccfg.samples_per_pixel = 1
+            t0 = time.perf_counter()
+            orc.o1_render(b.graph_ptr(), world, cam, ccfg, height, threads=cores)
+            dt1 = max(1e-3, time.perf_counter() - t0)
+            cpu_spp = int(max(1, min(spp, round(args.cpu_seconds / dt1))))
+            ccfg.samples_per_pixel = cpu_spp
             t0 = time.perf_counter()
             orc.o1_render(b.graph_ptr(), world, cam, ccfg, height, threads=cores)
             dt = time.perf_counter() - t0

@@ -13,6 +13,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Load order matters when torch and librtx_hip.so share a process: torch bundles its own
+    # libamdhip64.so.7, librtx_hip.so links the system one (same soname).  Whichever loads first is the
+    # one both use; torch only finds the GPU through its own copy, so torch goes first (bench.py does
+    # the same).  Device pointers are then interchangeable between torch and the library.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def _build_mod():

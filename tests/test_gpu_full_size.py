@@ -1,0 +1,85 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need a full CPU render:
+
+  * spot rows: any image row is a pure function of (scene, camera, config, row), so a handful of rows
+    rendered by the CPU oracle at FULL spp must equal the same rows of the full GPU frame bit for bit;
+  * shards: the frame rendered as N row shards (what N GPUs would do) reassembles to the unsharded frame;
+  * passes: splitting the samples over several sample-buffer passes changes nothing;
+  * idempotence: rendering twice gives the same bytes.
+"""
+import importlib
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _checksum(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def _render_rows_device(rtsr, scene, cam, cfg, shard):
+    import torch
+    rows = rtsr.shard_rows(cfg, shard)
+    w = cfg.image_width
+    d_acc = torch.zeros(rows * w * 3, dtype=torch.float64, device="cuda")
+    d_rgb = torch.zeros(rows * w * 3, dtype=torch.uint8, device="cuda")
+    scene.render_device(cam, cfg, shard=shard, d_accum=d_acc.data_ptr(), d_rgb8=d_rgb.data_ptr(),
+                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_acc.cpu().numpy().reshape(rows, w, 3), d_rgb.cpu().numpy().reshape(rows, w, 3)
+
+
+def test_c2_full_frame_properties(rtsr, orc):
+    """BASELINE configs[1]: Book-1 final scene, 800x533, 500 spp, depth 50."""
+    rdist = importlib.import_module("ray-tracing-series-rust_amd.dist")
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(rtsr.SCENE_BOOK1_CANONICAL)
+    cfg = rtsr.Config.new(1.5, 800, 500, 50, 10, seed=1, background=bg)
+    h = rtsr.image_height(cfg)
+    assert h == 533
+    flat = b.flatten(world)
+    scene = flat.upload()
+    full = scene.render(cam, cfg)
+    assert np.isfinite(full.accum).all() and full.accum.min() >= 0.0
+    # idempotence
+    again = scene.render(cam, cfg, want_accum=False)
+    assert _checksum(again.rgb8) == _checksum(full.rgb8)
+    # spot rows vs the CPU oracle at full spp: rows {j : j % 107 == 5} = 5 rows (sky, horizon, spheres, ground)
+    shard = (5, 107, 1)
+    rows = rdist.shard_row_indices(h, shard)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=shard, threads=32)
+    assert np.array_equal(full.accum[rows], ref_accum)
+    assert np.array_equal(full.rgb8[rows], ref_rgb8)
+    # shards reassemble (3 ranks, interleaved rows) -- checksum of checksums
+    parts = [_render_rows_device(rtsr, scene, cam, cfg, (r, 3, 1)) for r in range(3)]
+    acc = rdist.assemble([p[0] for p in parts], h, 800, 3, 1)
+    rgb = rdist.assemble([p[1] for p in parts], h, 800, 3, 1)
+    assert np.array_equal(acc, full.accum) and _checksum(rgb) == _checksum(full.rgb8)
+    # several passes (sample buffer capped at 1 GiB -> 5 passes)
+    cfg2 = rtsr.RtxConfig.from_buffer_copy(cfg)
+    cfg2.sample_buffer_bytes = 1 << 30
+    multi = scene.render(cam, cfg2)
+    assert np.array_equal(multi.accum, full.accum)
+
+
+@pytest.mark.parametrize("name,sid,width,aspect,spp,opts,stride", [
+    ("book2_final_1000x1000", 6, 1000, 1.0, 16, {}, 97),                                  # configs[2] geometry, reduced spp
+    ("dragon_871k_1920x1080", 11, 1920, 16.0 / 9.0, 2, {"mesh_triangles": 871200}, 181),  # configs[3] geometry, reduced spp
+    ("book1_head_800x450", 13, 800, 16.0 / 9.0, 32, {}, 89),
+])
+def test_full_resolution_spot_rows(rtsr, orc, name, sid, width, aspect, spp, opts, stride):
+    rdist = importlib.import_module("ray-tracing-series-rust_amd.dist")
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(sid, **opts)
+    cfg = rtsr.Config.new(aspect, width, spp, 50, 10, seed=1, background=bg)
+    h = rtsr.image_height(cfg)
+    flat = b.flatten(world)
+    full = flat.upload().render(cam, cfg)
+    shard = (3, stride, 1)
+    rows = rdist.shard_row_indices(h, shard)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=shard, threads=32)
+    diff = np.abs(full.accum[rows] - ref_accum).max(axis=2)
+    assert np.array_equal(full.accum[rows], ref_accum), "%d pixels differ" % int((diff > 0).sum())
+    assert np.array_equal(full.rgb8[rows], ref_rgb8)
