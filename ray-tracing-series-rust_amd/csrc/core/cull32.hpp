@@ -29,8 +29,8 @@ struct Ray32 {
   float t_min;          // rounded down
 };
 
-RT_HD float cull_round_up(double x) {  // smallest-effort f32 >= x for x >= 0 (inf stays inf)
-  return (float)x * 1.00000012f;
+RT_HD float cull_round_up(double x) {  // an f32 >= x (inf stays inf)
+  return (float)x * (x >= 0.0 ? 1.00000012f : 0.99999988f);
 }
 
 RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
@@ -44,7 +44,8 @@ RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
   float ay = __builtin_fabsf(q.iy) < 1e30f ? __builtin_fabsf(q.oiy) : 0.0f;
   float az = __builtin_fabsf(q.iz) < 1e30f ? __builtin_fabsf(q.oiz) : 0.0f;
   q.err = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az)) * 0x1.0p-21f;
-  q.t_min = (float)t_min * 0.99999988f;
+  // rounded DOWN whatever the sign (a medium's second boundary query may start at a negative t)
+  q.t_min = (float)t_min * (t_min >= 0.0 ? 0.99999988f : 1.00000012f);
   return q;
 }
 

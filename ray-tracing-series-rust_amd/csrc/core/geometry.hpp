@@ -39,8 +39,8 @@ RT_HD void create_normal_face(const Ray& r, Vec3 outward_normal, Vec3* normal, b
   *front_face = ff;
 }
 
-// hit.rs:195-200
-RT_HD void get_sphere_uv(Point3 p, double* u, double* v) {
+// hit.rs:195-200.  Out of line: only Image-textured spheres use uv, and acos/atan2 are long.
+RT_HD_NOINLINE void get_sphere_uv(Point3 p, double* u, double* v) {
   double theta = rt_acos(-p.y);
   double phi = rt_atan2(-p.z, p.x) + RT_PI;
   *u = phi / (2.0 * RT_PI);
@@ -94,16 +94,10 @@ RT_HD bool triangle_t(const FlatTriangle& tr, const Ray& r, double t_min, double
   return true;
 }
 
-// hit.rs:476-485 (Xy), 541-550 (Xz), 606-615 (Yz).
-RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, double* t_out) {
-  double ok, dk, oa, da, ob, db;
-  if (q.axis == RECT_XY) {
-    ok = r.origin.z; dk = r.direction.z; oa = r.origin.x; da = r.direction.x; ob = r.origin.y; db = r.direction.y;
-  } else if (q.axis == RECT_XZ) {
-    ok = r.origin.y; dk = r.direction.y; oa = r.origin.x; da = r.direction.x; ob = r.origin.z; db = r.direction.z;
-  } else {
-    ok = r.origin.x; dk = r.direction.x; oa = r.origin.y; da = r.direction.y; ob = r.origin.z; db = r.direction.z;
-  }
+// hit.rs:476-485 (Xy), 541-550 (Xz), 606-615 (Yz).  One body per axis, each naming the ray
+// components it reads (a runtime-selected member turns into an indexed stack load on the GPU).
+RT_HD bool rect_core(const FlatRect& q, double ok, double dk, double oa, double da, double ob, double db,
+                     double t_min, double t_max, double* t_out) {
   double t = (q.k - ok) / dk;
   if (t < t_min || t > t_max) return false;
   double x = oa + t * da;
@@ -111,6 +105,13 @@ RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, d
   if (x < q.a0 || x > q.a1 || y < q.b0 || y > q.b1) return false;
   *t_out = t;
   return true;
+}
+RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, double* t_out) {
+  if (q.axis == RECT_XY)
+    return rect_core(q, r.origin.z, r.direction.z, r.origin.x, r.direction.x, r.origin.y, r.direction.y, t_min, t_max, t_out);
+  if (q.axis == RECT_XZ)
+    return rect_core(q, r.origin.y, r.direction.y, r.origin.x, r.direction.x, r.origin.z, r.direction.z, t_min, t_max, t_out);
+  return rect_core(q, r.origin.x, r.direction.x, r.origin.y, r.direction.y, r.origin.z, r.direction.z, t_min, t_max, t_out);
 }
 
 template <uint32_t F, bool COUNT>
@@ -170,20 +171,26 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
   if ((F & F_RECT) && (type == PRIM_RECT || !(F & F_TRIANGLE))) {
     // hit.rs:486-500, 551-565, 616-630
     const FlatRect& q = sv.rects[idx];
-    double oa, da, ob, db;
-    Vec3 outward;
-    if (q.axis == RECT_XY) { oa = r.origin.x; da = r.direction.x; ob = r.origin.y; db = r.direction.y; outward = v3(0, 0, 1); }
-    else if (q.axis == RECT_XZ) { oa = r.origin.x; da = r.direction.x; ob = r.origin.z; db = r.direction.z; outward = v3(0, 1, 0); }
-    else { oa = r.origin.y; da = r.direction.y; ob = r.origin.z; db = r.direction.z; outward = v3(1, 0, 0); }
     rec->u = 0.0; rec->v = 0.0;
-    if (F & F_IMAGE) {
-      if (sv.materials[q.mat].needs_uv) {
-        double x = oa + t * da, y = ob + t * db;
-        rec->u = (x - q.a0) / (q.a1 - q.a0);
-        rec->v = (y - q.b0) / (q.b1 - q.b0);
+    if (q.axis == RECT_XY) {
+      if ((F & F_IMAGE) && sv.materials[q.mat].needs_uv) {
+        rec->u = ((r.origin.x + t * r.direction.x) - q.a0) / (q.a1 - q.a0);
+        rec->v = ((r.origin.y + t * r.direction.y) - q.b0) / (q.b1 - q.b0);
       }
+      create_normal_face(r, v3(0, 0, 1), &rec->normal, &rec->front_face);
+    } else if (q.axis == RECT_XZ) {
+      if ((F & F_IMAGE) && sv.materials[q.mat].needs_uv) {
+        rec->u = ((r.origin.x + t * r.direction.x) - q.a0) / (q.a1 - q.a0);
+        rec->v = ((r.origin.z + t * r.direction.z) - q.b0) / (q.b1 - q.b0);
+      }
+      create_normal_face(r, v3(0, 1, 0), &rec->normal, &rec->front_face);
+    } else {
+      if ((F & F_IMAGE) && sv.materials[q.mat].needs_uv) {
+        rec->u = ((r.origin.y + t * r.direction.y) - q.a0) / (q.a1 - q.a0);
+        rec->v = ((r.origin.z + t * r.direction.z) - q.b0) / (q.b1 - q.b0);
+      }
+      create_normal_face(r, v3(1, 0, 0), &rec->normal, &rec->front_face);
     }
-    create_normal_face(r, outward, &rec->normal, &rec->front_face);
     rec->mat = q.mat;
     return;
   }
@@ -309,8 +316,19 @@ RT_HD void bvh_closest(const SceneView& sv, int32_t root, uint32_t first_ref, co
   }
 }
 
+// How a BVH entry is walked.  SerialWalk is the portable one (CPU checker, simple kernels); the
+// device supplies a wave-cooperative walker (hip/render.hip VoteWalk).  Any walker must return the
+// closest hit under offer_prim's rule, so the choice is invisible in results.
+struct SerialWalk {
+  template <uint32_t F, bool COUNT, class STACK>
+  RT_HD static void run(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r, double t_min,
+                        Closest* best, STACK& stack, TraceCounters* cnt) {
+    bvh_closest<F, COUNT>(sv, root, first_ref, r, t_min, best, stack, cnt);
+  }
+};
+
 // PRIM / GROUP / BVH entries: find the closest candidate in [t_min, t_max].
-template <uint32_t F, bool COUNT, class STACK>
+template <uint32_t F, bool COUNT, class STACK, class WALK = SerialWalk>
 RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, double t_min,
                         double t_max, Closest* best, STACK& stack, TraceCounters* cnt) {
   best->t = t_max;
@@ -318,7 +336,7 @@ RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, d
   best->ref = 0;
   best->order = 0;
   if ((F & F_BVH) && (e.kind == ENTRY_BVH || !(F & (F_PRIM_ENTRY | F_GROUP)))) {
-    bvh_closest<F, COUNT>(sv, e.a, (uint32_t)e.b, r, t_min, best, stack, cnt);
+    WALK::template run<F, COUNT>(sv, e.a, (uint32_t)e.b, r, t_min, best, stack, cnt);
     return;
   }
   if ((F & F_PRIM_ENTRY) && (e.kind == ENTRY_PRIM || !(F & F_GROUP))) {
@@ -378,7 +396,7 @@ RT_HD void xform_record(const FlatXformOp& op, const Ray& child_ray, HitRecord* 
 // A ConstantMedium asks its boundary twice (rec1 over (-inf, inf), rec2 from rec1.t + 0.0001),
 // then draws one uniform from the path's stream -- inside the intersection, exactly where
 // the reference draws it (hit.rs:969).
-template <uint32_t F, bool COUNT, class STACK>
+template <uint32_t F, bool COUNT, class STACK, class WALK = SerialWalk>
 RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_max, HitRecord* rec,
                      Rng& rng, STACK& stack, TraceCounters* cnt) {
   if (COUNT) cnt->rays++;
@@ -388,18 +406,18 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
     const FlatEntry* e = &sv.entries[sv.top_level[i]];
     const bool is_medium = (F & F_MEDIUM) && e->kind == ENTRY_MEDIUM;
     const FlatEntry* solid = is_medium ? &sv.entries[e->a] : e;
-    // rays through the (up to two) transform ops, outermost first
+    // the ray as the innermost geometry sees it (up to two transform ops, outermost first); the
+    // intermediate ray is recomputed for the way back instead of being kept live across the walk
     const bool is_xform = (F & F_XFORM) && solid->kind == ENTRY_XFORM;
-    Ray r1 = r, r2 = r;
+    Ray rq = r;
     const FlatEntry* geom = solid;
     int nops = 0;
     if (is_xform) {
       nops = solid->b;
       geom = &sv.entries[solid->a];
-      r1 = xform_ray(solid->ops[0], r);
-      r2 = (nops > 1) ? xform_ray(solid->ops[1], r1) : r1;
+      rq = xform_ray(solid->ops[0], r);
+      if (nops > 1) rq = xform_ray(solid->ops[1], rq);
     }
-    const Ray& rq = is_xform ? r2 : r;
 
     Closest best;
     double q_min = is_medium ? -RT_INFINITY : t_min;
@@ -408,13 +426,14 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
     bool ok = true;
     const int n_query = is_medium ? 2 : 1;
     for (int q = 0; q < n_query; ++q) {
-      geom_closest<F, COUNT>(sv, *geom, rq, q_min, q_max, &best, stack, cnt);
+      geom_closest<F, COUNT, STACK, WALK>(sv, *geom, rq, q_min, q_max, &best, stack, cnt);
       if (!best.hit) { ok = false; break; }
       if (q == 0) { rec1_t = best.t; q_min = rec1_t + 0.0001; }
     }
     if (!ok) continue;
 
-    HitRecord tmp;
+    // every accepted hit replaces the running record (range rejection already compared against
+    // closest_so_far), so the record is built in place
     if (is_medium) {
       double rec2_t = best.t;
       double t1 = rt_fmax(rec1_t, t_min);
@@ -426,22 +445,25 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
       double hit_distance = e->f[0] * rt_log(rng_f64(rng));
       if (hit_distance > distance_inside_boundary) continue;
       double t = t1 + hit_distance / ray_length;
-      tmp.t = t;
-      tmp.p = ray_at(r, t);
-      tmp.normal = v3(0, 0, 0);
-      tmp.front_face = true;
-      tmp.u = 0.0; tmp.v = 0.0;
-      tmp.mat = e->b;
+      rec->t = t;
+      rec->p = ray_at(r, t);
+      rec->normal = v3(0, 0, 0);
+      rec->front_face = true;
+      rec->u = 0.0; rec->v = 0.0;
+      rec->mat = e->b;
     } else {
-      prim_finalize<F>(sv, best.ref, rq, best.t, &tmp);
+      prim_finalize<F>(sv, best.ref, rq, best.t, rec);
       if (is_xform) {
-        if (nops > 1) xform_record(solid->ops[1], r2, &tmp);
-        xform_record(solid->ops[0], r1, &tmp);
+        if (nops > 1) {
+          xform_record(solid->ops[1], rq, rec);
+          xform_record(solid->ops[0], xform_ray(solid->ops[0], r), rec);
+        } else {
+          xform_record(solid->ops[0], rq, rec);
+        }
       }
     }
     hit_anything = true;
-    closest_so_far = tmp.t;
-    *rec = tmp;
+    closest_so_far = rec->t;
   }
   return hit_anything;
 }

@@ -63,12 +63,12 @@ RT_HD bool path_bounce_end(const SceneView& sv, const RenderParams& rp, PathStat
   return false;
 }
 
-template <uint32_t F, bool COUNT, class STACK>
+template <uint32_t F, bool COUNT, class STACK, class WALK = SerialWalk>
 RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps, STACK& stack,
                      TraceCounters* cnt) {
   if (path_bounce_begin(ps)) return true;
   HitRecord rec;
-  bool hit = world_hit<F, COUNT>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt);
+  bool hit = world_hit<F, COUNT, STACK, WALK>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt);
   return path_bounce_end<F, COUNT>(sv, rp, ps, hit, rec, cnt);
 }
 

@@ -11,10 +11,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define RT_HD __host__ __device__ __forceinline__
-#define RT_HD_NOINLINE __host__ __device__
+#define RT_HD_NOINLINE __host__ __device__ __attribute__((noinline)) inline
 #else
 #define RT_HD inline
-#define RT_HD_NOINLINE
+#define RT_HD_NOINLINE __attribute__((noinline)) inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -85,6 +85,29 @@ RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceC
   return rt_fabs(accum);
 }
 
+// The two expensive, rarely reached texture kinds, kept out of line so that their registers and
+// code do not weigh on the bounce loop (Noise: 7 Perlin octaves; Image: a texel fetch).
+template <bool COUNT>
+RT_HD_NOINLINE Color texture_value_cold(const SceneView& sv, const FlatTexture& t, double u, double v, Point3 p,
+                                        TraceCounters* cnt) {
+  if (t.kind == TEX_NOISE) {  // texture.rs:80-88
+    double s = 1.0 + rt_sin(t.scale * p.z + 10.0 * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
+    return v3(1.0, 1.0, 1.0) * 0.5 * s;
+  }
+  // TEX_IMAGE, texture.rs:102-121
+  if (COUNT) cnt->texels++;
+  const FlatImage& im = sv.images[t.a];
+  double uc = clamp(u, 0.0, 1.0);
+  double vc = 1.0 - clamp(v, 0.0, 1.0);
+  int32_t i = rt_f64_as_i32(uc * (double)im.width);
+  int32_t j = rt_f64_as_i32(vc * (double)im.height);
+  i = i < im.width - 1 ? i : im.width - 1;
+  j = j < im.height - 1 ? j : im.height - 1;
+  const double color_scale = 1.0 / 255.0;
+  const double* px = sv.texels + 3 * (im.first_texel + (int64_t)j * im.width + i);
+  return v3(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
+}
+
 // Texture::value for the whole texture tree (texture.rs:27-31, 54-64, 80-88, 102-121).
 // Checker picks a child from p alone, so nested checkers resolve iteratively.
 template <uint32_t F, bool COUNT>
@@ -99,23 +122,8 @@ RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, 
     }
   }
   const FlatTexture& t = sv.textures[tex];
-  if ((F & F_NOISE) && t.kind == TEX_NOISE) {
-    double s = 1.0 + rt_sin(t.scale * p.z + 10.0 * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
-    return v3(1.0, 1.0, 1.0) * 0.5 * s;
-  }
-  if ((F & F_IMAGE) && t.kind == TEX_IMAGE) {
-    if (COUNT) cnt->texels++;
-    const FlatImage& im = sv.images[t.a];
-    double uc = clamp(u, 0.0, 1.0);
-    double vc = 1.0 - clamp(v, 0.0, 1.0);
-    int32_t i = rt_f64_as_i32(uc * (double)im.width);
-    int32_t j = rt_f64_as_i32(vc * (double)im.height);
-    i = i < im.width - 1 ? i : im.width - 1;
-    j = j < im.height - 1 ? j : im.height - 1;
-    const double color_scale = 1.0 / 255.0;
-    const double* px = sv.texels + 3 * (im.first_texel + (int64_t)j * im.width + i);
-    return v3(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
-  }
+  if ((F & (F_NOISE | F_IMAGE)) && (t.kind == TEX_NOISE || t.kind == TEX_IMAGE))
+    return texture_value_cold<COUNT>(sv, t, u, v, p, cnt);
   return load_v3(t.color);  // TEX_SOLID
 }
 

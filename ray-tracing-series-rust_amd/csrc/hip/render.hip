@@ -170,6 +170,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_simple(rt::SceneView sv, 
   if (COUNT) flush_counters(cnt, counters);
 }
 
+struct VoteWalk;  // wave-cooperative BVH walker, defined with the voting walk below
+
 // Persistent waves with path regeneration.  The pass's samples form one index space
 // [0, total); waves pull chunks of it from a global counter and hand indices to their lanes
 // as lanes finish paths: every loop iteration the lanes without a path are compacted with a
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView 
     }
     if (__ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
     if (active) {
-      if (rt::path_step<F, false>(sv, rp, &ps, stack, nullptr)) {
+      if (rt::path_step<F, false, LdsStack, VoteWalk>(sv, rp, &ps, stack, nullptr)) {
         double* o = samples + 3 * (size_t)g;
         o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
         active = false;
@@ -409,6 +411,36 @@ __device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t
     rt::offer_prim<F, false>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, nullptr);
   *cur = stack.empty() ? WALK_DONE : stack.pop();
 }
+
+// The voting walk as a world_hit walker policy (core/geometry.hpp): every lane that reaches a BVH
+// entry walks it together with the rest of its wave.  Top-level entry kinds are the same for all
+// lanes, so the enclosing control flow is wave-uniform up to lanes that already missed.
+struct VoteWalk {
+  template <uint32_t F, bool COUNT, class STACK>
+  __device__ __forceinline__ static void run(const rt::SceneView& sv, int32_t root, uint32_t first_ref,
+                                             const rt::Ray& r, double t_min, rt::Closest* best, STACK& stack,
+                                             rt::TraceCounters*) {
+    rt::Ray32 q = rt::make_ray32(r, t_min);
+    uint32_t dir_neg = rt::ray_dir_neg(r);
+    float t_max32 = rt::cull_round_up(best->t);
+    stack.reset();
+    int32_t cur = root;
+    for (;;) {
+      bool is_leaf = cur < 0;
+      bool is_node = !is_leaf && cur != WALK_DONE;
+      unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
+      if ((m_node | m_leaf) == 0ull) break;
+      if ((uint32_t)__popcll(m_node) * 3u >= (uint32_t)__popcll(m_leaf)) {
+        if (is_node) walk_node_step32(sv, q, dir_neg, t_max32, &cur, stack);
+      } else {
+        if (is_leaf) {
+          walk_leaf_step<F>(sv, first_ref, r, t_min, best, &cur, stack);
+          t_max32 = rt::cull_round_up(best->t);
+        }
+      }
+    }
+  }
+};
 
 // k_trace_persistent with the deferred-leaf walk, for worlds that are one BVH.
 // DIAG: per-region occupancy counters (diag[2k] = times the wave executed region k, diag[2k+1] = lanes
