@@ -173,7 +173,7 @@ def main():
                         pmc = rec.get("hbm_bytes_per_launch")
                 except Exception:
                     pmc = None
-            roofline = {"bound": "hbm", "kernel": "k_trace_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": "k_trace_vote" if args.workload in ("c1", "c2", "c5", "head") else "k_trace_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc,
                         "bytes_per_sample": round(bytes_per_sample, 1), "kernel_ms": round(mean_trace_ms, 3),
                         "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),

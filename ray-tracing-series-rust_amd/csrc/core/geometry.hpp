@@ -40,7 +40,7 @@ RT_HD void create_normal_face(const Ray& r, Vec3 outward_normal, Vec3* normal, b
 }
 
 // hit.rs:195-200.  Out of line: only Image-textured spheres use uv, and acos/atan2 are long.
-RT_HD_NOINLINE void get_sphere_uv(Point3 p, double* u, double* v) {
+RT_HD void get_sphere_uv(Point3 p, double* u, double* v) {
   double theta = rt_acos(-p.y);
   double phi = rt_atan2(-p.z, p.x) + RT_PI;
   *u = phi / (2.0 * RT_PI);

@@ -17,6 +17,16 @@
 #define RT_HD_NOINLINE __attribute__((noinline)) inline
 #endif
 
+// Keep a loop rolled (the device compiler otherwise unrolls Perlin's 7 octaves x 8 corners and keeps
+// every gradient fetch live: hundreds of registers for a rarely taken path).
+#if defined(__clang__)
+#define RT_NO_UNROLL _Pragma("clang loop unroll(disable)")
+#elif defined(__GNUC__)
+#define RT_NO_UNROLL _Pragma("GCC unroll 1")
+#else
+#define RT_NO_UNROLL
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_DEVICE_CODE 1
 #else

@@ -58,8 +58,11 @@ RT_HD double perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
   double vv = v * v * (3.0 - 2.0 * v);
   double ww = w * w * (3.0 - 2.0 * w);
   double accum = 0.0;
+  RT_NO_UNROLL
   for (uint32_t di = 0; di < 2; ++di)
+    RT_NO_UNROLL
     for (uint32_t dj = 0; dj < 2; ++dj)
+      RT_NO_UNROLL
       for (uint32_t dk = 0; dk < 2; ++dk) {
         int32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
         Vec3 c = load_v3(pn.ranvec[h]);
@@ -77,6 +80,7 @@ RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceC
   double accum = 0.0;
   Point3 temp_p = p;
   double weight = 1.0;
+  RT_NO_UNROLL
   for (int i = 0; i < depth; ++i) {
     accum += weight * perlin_noise<COUNT>(pn, temp_p, cnt);
     weight *= 0.5;
@@ -88,7 +92,7 @@ RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceC
 // The two expensive, rarely reached texture kinds, kept out of line so that their registers and
 // code do not weigh on the bounce loop (Noise: 7 Perlin octaves; Image: a texel fetch).
 template <bool COUNT>
-RT_HD_NOINLINE Color texture_value_cold(const SceneView& sv, const FlatTexture& t, double u, double v, Point3 p,
+RT_HD Color texture_value_cold(const SceneView& sv, const FlatTexture& t, double u, double v, Point3 p,
                                         TraceCounters* cnt) {
   if (t.kind == TEX_NOISE) {  // texture.rs:80-88
     double s = 1.0 + rt_sin(t.scale * p.z + 10.0 * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
