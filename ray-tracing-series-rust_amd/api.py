@@ -51,7 +51,8 @@ class RtxSceneOptions(C.Structure):
 
 
 class RtxBuildOptions(C.Structure):
-    _fields_ = [("max_leaf", C.c_int32), ("sah_bins", C.c_int32)]
+    _fields_ = [("max_leaf", C.c_int32), ("sah_bins", C.c_int32), ("reference_bvh", C.c_int32), ("reserved", C.c_int32),
+                ("bvh_seed", C.c_uint64)]
 
 
 class RtxFlatInfo(C.Structure):
@@ -330,15 +331,15 @@ class Builder:
         _check(lib.rtx_get_world_cam(self._p, scene_id, C.byref(opt), C.byref(world), C.byref(cam), bg))
         return world.value, cam, (bg[0], bg[1], bg[2])
 
-    def flatten(self, world, max_leaf=0, sah_bins=0):
-        return Flat(self, world, max_leaf, sah_bins)
+    def flatten(self, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0):
+        return Flat(self, world, max_leaf, sah_bins, reference_bvh, bvh_seed)
 
 
 class Flat:
     """Flattened scene in host memory (rtx_flat)."""
 
-    def __init__(self, builder, world, max_leaf=0, sah_bins=0):
-        opt = RtxBuildOptions(max_leaf, sah_bins)
+    def __init__(self, builder, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0):
+        opt = RtxBuildOptions(max_leaf, sah_bins, 1 if reference_bvh else 0, 0, bvh_seed)
         p = _VP()
         _check(lib.rtx_flatten(builder.ptr, world, C.byref(opt), C.byref(p)))
         self._p = p

@@ -167,6 +167,8 @@ rtx_status rtx_flatten(const rtx_builder* b, rtx_handle world, const RtxBuildOpt
   if (options) {
     if (options->max_leaf > 0) opt.max_leaf = options->max_leaf;
     if (options->sah_bins > 0) opt.sah_bins = options->sah_bins;
+    opt.reference_bvh = options->reference_bvh ? 1 : 0;
+    if (options->bvh_seed) opt.bvh_seed = options->bvh_seed;
   }
   rtx_flat* f = new (std::nothrow) rtx_flat();
   if (!f) { set_error("out of memory"); return RTX_ENOMEM; }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include "../core/rng.hpp"
 #include "flat_scene.hpp"
 
 namespace rtx {
@@ -173,6 +174,63 @@ int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
   int32_t root = bf.build(0, (uint32_t)n, &root_box, depth);
   if (sah_cost) *sah_cost += bf.sah;
   return root;
+}
+
+// bvh.rs:14-83, node for node (see flat_scene.hpp).  The reference clones the object vector at
+// every node and sorts the [start, end) slice of its clone; sorting disjoint slices of one index
+// vector in place yields the same tree.
+namespace {
+struct RefBuilder {
+  const std::vector<double>& boxes;
+  const std::vector<double>& sort_boxes;
+  std::vector<rt::FlatNode>* nodes;
+  std::vector<uint32_t>& idx;
+  rt::HostRng rng;
+  int32_t build(uint32_t start, uint32_t end, Box* out, int32_t* depth) {
+    int axis = (int)rt::host_rng_below(rng, 2);  // bvh.rs:24: gen_range(0..2), z is never chosen
+    auto less = [&](uint32_t a, uint32_t b) { return sort_boxes[6 * (size_t)a + axis] < sort_boxes[6 * (size_t)b + axis]; };
+    uint32_t span = end - start;
+    size_t me = nodes->size();
+    nodes->emplace_back();
+    Box b0, b1;
+    int32_t c0, c1, d0 = 0, d1 = 0;
+    auto leaf = [&](uint32_t slot, Box* bx) { bx->reset(); bx->grow(&boxes[6 * (size_t)idx[slot]]); return rt::make_leaf(slot, 1); };
+    if (span == 1) {          // bvh.rs:53-55: left = right = the same object
+      c0 = leaf(start, &b0); c1 = leaf(start, &b1);
+    } else if (span == 2) {   // bvh.rs:56-63
+      if (!less(idx[start], idx[start + 1])) std::swap(idx[start], idx[start + 1]);
+      c0 = leaf(start, &b0); c1 = leaf(start + 1, &b1);
+    } else {                  // bvh.rs:64-68
+      std::stable_sort(idx.begin() + start, idx.begin() + end, less);
+      uint32_t mid = start + span / 2;
+      c0 = build(start, mid, &b0, &d0);
+      c1 = build(mid, end, &b1, &d1);
+    }
+    rt::FlatNode& nd = (*nodes)[me];
+    for (int a = 0; a < 3; ++a) {
+      nd.bmin[0][a] = b0.mn[a]; nd.bmax[0][a] = b0.mx[a];
+      nd.bmin[1][a] = b1.mn[a]; nd.bmax[1][a] = b1.mx[a];
+    }
+    nd.child[0] = c0; nd.child[1] = c1;
+    nd.pad[0] = axis; nd.pad[1] = 0;
+    *out = b0; out->grow(b1);
+    *depth = 1 + std::max(d0, d1);
+    return (int32_t)me;
+  }
+};
+}  // namespace
+
+int32_t build_bvh_reference(const std::vector<double>& boxes, const std::vector<double>& sort_boxes,
+                            uint64_t seed, std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order,
+                            int32_t* depth) {
+  size_t n = boxes.size() / 6;
+  order->resize(n);
+  for (size_t i = 0; i < n; ++i) (*order)[i] = (uint32_t)i;
+  *depth = 0;
+  if (n < 1) return -1;
+  RefBuilder rb{boxes, sort_boxes, nodes, *order, rt::HostRng{seed}};
+  Box root;
+  return rb.build(0, (uint32_t)n, &root, depth);
 }
 
 }  // namespace rtx

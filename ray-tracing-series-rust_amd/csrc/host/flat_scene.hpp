@@ -57,6 +57,11 @@ struct FlatScene {
 struct BuildOptions {
   int max_leaf = 2;   // primitives per BVH leaf (1..8)
   int sah_bins = 32;
+  // 1: build every BVH with the REFERENCE's rule instead of SAH (bvh.rs:14-83: random axis in {x, y},
+  // stable sort by the time-(0,0) box minimum, median split, one object per leaf, a span of one stored
+  // twice).  Same image, different traversal statistics -- an A/B switch.
+  int reference_bvh = 0;
+  uint64_t bvh_seed = 1;
 };
 
 // Flatten `world` (any Hittable handle of `g`).  Returns false and sets *err when the graph
@@ -71,5 +76,10 @@ bool flatten_scene(const SceneGraph& g, int32_t world, const BuildOptions& opt, 
 int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
                   std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order, int32_t* depth,
                   double* sah_cost);
+// The reference's builder.  `sort_boxes` are the bounding_box(0.0, 0.0) boxes its comparator uses
+// (bvh.rs:27-28), `boxes` the (time0, time1) boxes the node bounds are made of (bvh.rs:71-78).
+int32_t build_bvh_reference(const std::vector<double>& boxes, const std::vector<double>& sort_boxes,
+                            uint64_t seed, std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order,
+                            int32_t* depth);
 
 }  // namespace rtx

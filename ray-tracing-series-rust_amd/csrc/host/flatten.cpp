@@ -193,12 +193,19 @@ struct Flattener {
       std::vector<rt::PrimRef> refs;
       for (int32_t c : o.children)
         if (!collect_prims(c, &refs)) return -1;
-      if (refs.size() < 2) return emit_group(refs);
+      if (refs.size() < 2 && !opt.reference_bvh) return emit_group(refs);
       std::vector<double> boxes(6 * refs.size());
       for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], o.f[0], o.f[1], &boxes[6 * i]);
       std::vector<uint32_t> order;
       int32_t depth = 0;
-      int32_t root = build_bvh(boxes, opt, &out.nodes, &order, &depth, &out.sah_cost);
+      int32_t root;
+      if (opt.reference_bvh) {
+        std::vector<double> sort_boxes(6 * refs.size());
+        for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], 0.0, 0.0, &sort_boxes[6 * i]);
+        root = build_bvh_reference(boxes, sort_boxes, opt.bvh_seed + (uint64_t)out.n_bvh, &out.nodes, &order, &depth);
+      } else {
+        root = build_bvh(boxes, opt, &out.nodes, &order, &depth, &out.sah_cost);
+      }
       rt::FlatEntry e = blank_entry(rt::ENTRY_BVH);
       e.a = root;
       e.b = (int32_t)out.refs.size();

@@ -272,35 +272,100 @@ int32_t SceneGraph::triangle_mesh(const double* vertices, int64_t n_vertices, co
 // model.rs:13-62: ASCII PLY.  Header lines are split on single spaces; "element vertex N" /
 // "element face N" give the counts; each vertex line contributes its first three tokens
 // times `scale`; each face line contributes tokens 1..3 (token 0 is the vertex count).
+// Beyond the reference: "format binary_little_endian 1.0" files are read too --
+// the first three vertex properties are x, y, z (any scalar type), further vertex properties are
+// skipped, a face is a list (count, indices...) whose first three indices are used.
+namespace {
+int ply_type_size(const std::string& t) {
+  if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+  if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+  if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+  if (t == "double" || t == "float64") return 8;
+  return 0;
+}
+double ply_read_scalar(const std::string& t, const unsigned char* p) {
+  if (t == "float" || t == "float32") { float v; memcpy(&v, p, 4); return (double)v; }
+  if (t == "double" || t == "float64") { double v; memcpy(&v, p, 8); return v; }
+  if (t == "char" || t == "int8") { int8_t v; memcpy(&v, p, 1); return (double)v; }
+  if (t == "uchar" || t == "uint8") { uint8_t v; memcpy(&v, p, 1); return (double)v; }
+  if (t == "short" || t == "int16") { int16_t v; memcpy(&v, p, 2); return (double)v; }
+  if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, p, 2); return (double)v; }
+  if (t == "int" || t == "int32") { int32_t v; memcpy(&v, p, 4); return (double)v; }
+  uint32_t v; memcpy(&v, p, 4); return (double)v;
+}
+}  // namespace
+
 int32_t SceneGraph::triangle_model(const char* path, double scale) {
   std::ifstream f(path, std::ios::binary);
   if (!f) { error = std::string("Couldn't open the file: ") + path; return -1; }
   std::string line;
   int64_t vertex_count = 0, face_count = 0;
-  bool got_end = false;
+  bool got_end = false, binary = false;
+  std::vector<std::string> vertex_props;
+  std::string face_count_type = "uchar", face_index_type = "int";
+  int in_element = 0;  // 1 vertex, 2 face
   while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
     if (line == "end_header") { got_end = true; break; }
-    char a[64], b[64];
-    long long n;
-    if (sscanf(line.c_str(), "%63s %63s %lld", a, b, &n) == 3 && strcmp(a, "element") == 0) {
-      if (strcmp(b, "vertex") == 0) vertex_count = n;
-      if (strcmp(b, "face") == 0) face_count = n;
+    char a[64] = {0}, b[64] = {0}, c[64] = {0}, d[64] = {0}, e[64] = {0};
+    int n = sscanf(line.c_str(), "%63s %63s %63s %63s %63s", a, b, c, d, e);
+    if (n >= 2 && strcmp(a, "format") == 0) {
+      if (strcmp(b, "binary_little_endian") == 0) binary = true;
+      else if (strcmp(b, "ascii") != 0) { error = std::string("ply: unsupported format ") + b; return -1; }
+    } else if (n >= 3 && strcmp(a, "element") == 0) {
+      if (strcmp(b, "vertex") == 0) { vertex_count = atoll(c); in_element = 1; }
+      else if (strcmp(b, "face") == 0) { face_count = atoll(c); in_element = 2; }
+      else in_element = 0;
+    } else if (n >= 3 && strcmp(a, "property") == 0) {
+      if (in_element == 1) vertex_props.push_back(b);
+      else if (in_element == 2 && strcmp(b, "list") == 0 && n >= 4) { face_count_type = c; face_index_type = d; }
     }
   }
   if (!got_end) { error = "ply: no end_header"; return -1; }
+  if (vertex_count < 0 || face_count < 0) { error = "ply: negative element count"; return -1; }
   std::vector<double> verts((size_t)3 * vertex_count);
-  for (int64_t i = 0; i < vertex_count; ++i) {
-    if (!std::getline(f, line)) { error = "ply: truncated vertex list"; return -1; }
-    double x, y, z;
-    if (sscanf(line.c_str(), "%lf %lf %lf", &x, &y, &z) != 3) { error = "ply: bad vertex line"; return -1; }
-    verts[3 * i] = x * scale; verts[3 * i + 1] = y * scale; verts[3 * i + 2] = z * scale;
-  }
   std::vector<int64_t> faces((size_t)3 * face_count);
-  for (int64_t i = 0; i < face_count; ++i) {
-    if (!std::getline(f, line)) { error = "ply: truncated face list"; return -1; }
-    long long n, a, b, c;
-    if (sscanf(line.c_str(), "%lld %lld %lld %lld", &n, &a, &b, &c) != 4) { error = "ply: bad face line"; return -1; }
-    faces[3 * i] = a; faces[3 * i + 1] = b; faces[3 * i + 2] = c;
+  if (!binary) {
+    for (int64_t i = 0; i < vertex_count; ++i) {
+      if (!std::getline(f, line)) { error = "ply: truncated vertex list"; return -1; }
+      double x, y, z;
+      if (sscanf(line.c_str(), "%lf %lf %lf", &x, &y, &z) != 3) { error = "ply: bad vertex line"; return -1; }
+      verts[3 * i] = x * scale; verts[3 * i + 1] = y * scale; verts[3 * i + 2] = z * scale;
+    }
+    for (int64_t i = 0; i < face_count; ++i) {
+      if (!std::getline(f, line)) { error = "ply: truncated face list"; return -1; }
+      long long n, a, b, c;
+      if (sscanf(line.c_str(), "%lld %lld %lld %lld", &n, &a, &b, &c) != 4) { error = "ply: bad face line"; return -1; }
+      faces[3 * i] = a; faces[3 * i + 1] = b; faces[3 * i + 2] = c;
+    }
+  } else {
+    if (vertex_props.size() < 3) { error = "ply: a vertex needs at least x y z"; return -1; }
+    size_t stride = 0;
+    for (const std::string& t : vertex_props) {
+      int sz = ply_type_size(t);
+      if (sz == 0) { error = "ply: unknown vertex property type " + t; return -1; }
+      stride += (size_t)sz;
+    }
+    std::vector<unsigned char> buf(stride);
+    for (int64_t i = 0; i < vertex_count; ++i) {
+      if (!f.read((char*)buf.data(), (std::streamsize)stride)) { error = "ply: truncated vertex data"; return -1; }
+      size_t off = 0;
+      for (int k = 0; k < 3; ++k) {
+        verts[3 * i + k] = ply_read_scalar(vertex_props[k], buf.data() + off) * scale;
+        off += (size_t)ply_type_size(vertex_props[k]);
+      }
+    }
+    int csz = ply_type_size(face_count_type), isz = ply_type_size(face_index_type);
+    if (csz == 0 || isz == 0) { error = "ply: unknown face list types"; return -1; }
+    std::vector<unsigned char> fb(8 * 256);
+    for (int64_t i = 0; i < face_count; ++i) {
+      unsigned char cb[8];
+      if (!f.read((char*)cb, csz)) { error = "ply: truncated face data"; return -1; }
+      int64_t n = (int64_t)ply_read_scalar(face_count_type, cb);
+      if (n < 3 || n > 255) { error = "ply: face with fewer than 3 (or more than 255) vertices"; return -1; }
+      if (!f.read((char*)fb.data(), (std::streamsize)(n * isz))) { error = "ply: truncated face data"; return -1; }
+      for (int k = 0; k < 3; ++k) faces[3 * i + k] = (int64_t)ply_read_scalar(face_index_type, fb.data() + (size_t)k * isz);
+    }
   }
   const double grey[3] = {0.2, 0.2, 0.2};  // model.rs:72
   int32_t mat = lambertian(solid_color(grey));

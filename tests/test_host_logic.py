@@ -137,3 +137,53 @@ def test_scene_catalogue_is_deterministic(rtsr):
     b = rtsr.Builder(43)
     world, _, _ = b.get_world_cam(rtsr.SCENE_BOOK1_HEAD)
     assert b.flatten(world).info() != infos[0][0]
+
+
+def test_reference_bvh_rule_same_image_more_box_tests(rtsr, orc):
+    """building the BVH with the reference's rule (bvh.rs:14-83) instead of SAH is an A/B switch:
+    identical image, very different traversal statistics."""
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(rtsr.SCENE_BOOK1_CANONICAL)
+    cfg = rtsr.Config.new(1.5, 48, 3, 50, 4, seed=3, background=bg)
+    f_sah = b.flatten(world)
+    f_ref = b.flatten(world, reference_bvh=True, bvh_seed=5)
+    f_ref2 = b.flatten(world, reference_bvh=True, bvh_seed=6)
+    a, _, c_sah = orc.o2_render(f_sah.arrays_ptr(), cam, cfg, 32, threads=8, counters=True)
+    a_ref, _, c_ref = orc.o2_render(f_ref.arrays_ptr(), cam, cfg, 32, threads=8, counters=True)
+    a_ref2, _ = orc.o2_render(f_ref2.arrays_ptr(), cam, cfg, 32, threads=8)
+    assert np.array_equal(a, a_ref) and np.array_equal(a, a_ref2)
+    assert c_ref["rays"] == c_sah["rays"]
+    assert c_ref["box_tests"] > 2 * c_sah["box_tests"]          # median split on a random x/y axis culls far worse
+    assert f_ref.info()["n_nodes"] >= f_sah.info()["n_nodes"]    # one object per leaf, spans of one stored twice
+
+
+def test_binary_ply_matches_ascii(rtsr, orc, tmp_path):
+    import struct
+    verts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
+    faces = [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3), (1, 2, 4)]
+    asc = tmp_path / "a.ply"
+    asc.write_text("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                   "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(verts), len(faces)) +
+                   "".join("%g %g %g\n" % v for v in verts) + "".join("3 %d %d %d\n" % f for f in faces))
+    binp = tmp_path / "b.ply"
+    header = ("ply\nformat binary_little_endian 1.0\ncomment extra vertex properties are skipped\nelement vertex %d\n"
+              "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty float confidence\n"
+              "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % (len(verts), len(faces))).encode()
+    body = b"".join(struct.pack("<fffBf", *map(float, v), 200, 0.5) for v in verts)
+    body += b"".join(struct.pack("<Biii", 3, *f) for f in faces)
+    binp.write_bytes(header + body)
+    cam = rtsr.Camera.new((3, 2, 4), (0.3, 0.3, 0.3), (0, 1, 0), 30.0, 1.0, 0.0, 5.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.0, 24, 2, 8, 1)
+    imgs = []
+    for path in (asc, binp):
+        b = rtsr.Builder(1)
+        world = b.bvh_from_list(b.triangle_model(str(path), 1.0), 0.0, 1.0)
+        flat = b.flatten(world)
+        assert flat.info()["n_triangles"] == len(faces)
+        imgs.append(orc.o2_render(flat.arrays_ptr(), cam, cfg, 24)[0])
+    assert np.array_equal(imgs[0], imgs[1])
+    b = rtsr.Builder(1)
+    bad = tmp_path / "c.ply"
+    bad.write_bytes(header + body[:-5])
+    with pytest.raises(rtsr.RtxError):
+        b.triangle_model(str(bad), 1.0)
