@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on a box with fewer GPUs than ranks (shards gathered through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true")
+    ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,7 +93,9 @@ def main():
     world, cam, bg = b.get_world_cam(sid, camera_aspect=aspect if sid in (100, 13) else 0.0)
     cfg = rtsr.Config.new(aspect, width, spp, depth, 10, seed=1, background=bg)
     height = rtsr.image_height(cfg)
-    flat = b.flatten(world)
+    t_flat = time.perf_counter()
+    flat = b.flatten(world, max_leaf=args.max_leaf)
+    t_flat = time.perf_counter() - t_flat
     scene = flat.upload()
 
     shard = (rank, world_size, 1)  # rows j with j % N == rank
@@ -208,7 +211,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": round(value / 1.4559, 1), "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "width": width, "height": height, "spp": spp, "max_depth": depth,
-                       "scene_seed": 1, "render_seed": 1, "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
+                       "scene_seed": 1, "render_seed": 1, "flatten_s": round(t_flat, 3), "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
                        if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_cpu_published": {"value": 1.4559, "unit": "Msamples/s", "source": "README.md:23, 10 threads, CPU unstated"},
