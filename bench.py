@@ -181,7 +181,8 @@ def main():
                         "bytes_per_sample": round(bytes_per_sample, 1), "kernel_ms": round(mean_trace_ms, 3),
                         "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),
                         "box_tests_per_ray": round(counts["box_tests"] / float(max(1, counts["rays"])), 2),
-                        "counted_on": "%d spp of the same pixels and seeds" % count_spp}
+                        "counted_on": "%d spp of the same pixels and seeds" % count_spp,
+                        "per_ray": {k: round(v / float(max(1, counts["rays"])), 3) for k, v in counts.items() if k not in ("rays", "samples") and v}}
         cpu = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

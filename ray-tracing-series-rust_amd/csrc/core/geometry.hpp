@@ -403,18 +403,22 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
   bool hit_anything = false;
   double closest_so_far = t_max;
   for (int32_t i = 0; i < sv.n_top_level; ++i) {
-    const FlatEntry* e = &sv.entries[sv.top_level[i]];
+    // the table walk is wave-uniform: entries are fetched once per wave (rt_load_uniform)
+    const FlatEntry e_rec = rt_load_uniform(&sv.entries[rt_load_uniform(&sv.top_level[i])]);
+    const FlatEntry* e = &e_rec;
     const bool is_medium = (F & F_MEDIUM) && e->kind == ENTRY_MEDIUM;
-    const FlatEntry* solid = is_medium ? &sv.entries[e->a] : e;
+    FlatEntry solid_rec = e_rec;
+    if (is_medium) solid_rec = rt_load_uniform(&sv.entries[e->a]);
+    const FlatEntry* solid = &solid_rec;
     // the ray as the innermost geometry sees it (up to two transform ops, outermost first); the
     // intermediate ray is recomputed for the way back instead of being kept live across the walk
     const bool is_xform = (F & F_XFORM) && solid->kind == ENTRY_XFORM;
     Ray rq = r;
-    const FlatEntry* geom = solid;
+    FlatEntry geom_rec = solid_rec;
     int nops = 0;
     if (is_xform) {
       nops = solid->b;
-      geom = &sv.entries[solid->a];
+      geom_rec = rt_load_uniform(&sv.entries[solid->a]);
       rq = xform_ray(solid->ops[0], r);
       if (nops > 1) rq = xform_ray(solid->ops[1], rq);
     }
@@ -426,7 +430,7 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
     bool ok = true;
     const int n_query = is_medium ? 2 : 1;
     for (int q = 0; q < n_query; ++q) {
-      geom_closest<F, COUNT, STACK, WALK>(sv, *geom, rq, q_min, q_max, &best, stack, cnt);
+      geom_closest<F, COUNT, STACK, WALK>(sv, geom_rec, rq, q_min, q_max, &best, stack, cnt);
       if (!best.hit) { ok = false; break; }
       if (q == 0) { rec1_t = best.t; q_min = rec1_t + 0.0001; }
     }

@@ -27,6 +27,19 @@
 #define RT_NO_UNROLL
 #endif
 
+// Load a record whose address is the same in every lane of a wave (the scene's top-level table).
+// On the device the read goes through the constant address space, which lets the compiler use
+// scalar loads (one fetch per wave into SGPRs) instead of 64 identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ T rt_load_uniform(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)(p);
+}
+#else
+template <class T>
+inline T rt_load_uniform(const T* p) { return *p; }
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_DEVICE_CODE 1
 #else

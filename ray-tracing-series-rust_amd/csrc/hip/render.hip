@@ -182,11 +182,28 @@ struct VoteWalk;  // wave-cooperative BVH walker, defined with the voting walk b
 // matter: streams are keyed by (pixel, sample) and every sample owns its output slot.
 #define TRACE_CHUNK 512u
 template <uint32_t F>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView sv, rt::RenderParams rp,
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView sv_in, rt::RenderParams rp,
                                                                    ShardMap sm, uint32_t s_begin,
                                                                    uint32_t total, uint32_t npix,
                                                                    double* __restrict__ samples,
-                                                                   unsigned int* work_counter) {
+                                                                   unsigned int* __restrict__ work_counter,
+                                                                   const rt::FlatEntry* __restrict__ entries_ro,
+                                                                   const int32_t* __restrict__ top_level_ro,
+                                                                   const rt::FlatSphere* __restrict__ spheres_ro,
+                                                                   const rt::FlatMovingSphere* __restrict__ msph_ro,
+                                                                   const rt::FlatRect* __restrict__ rects_ro,
+                                                                   const rt::FlatTriangle* __restrict__ tris_ro,
+                                                                   const rt::FlatMaterial* __restrict__ mats_ro,
+                                                                   const rt::FlatTexture* __restrict__ tex_ro,
+                                                                   const rt::PrimRef* __restrict__ refs_ro) {
+  // The world table is read through `const __restrict__` kernel parameters: that is what lets the
+  // compiler prove the kernel's own stores cannot clobber it and fetch the (wave-uniform) entries with
+  // scalar loads -- one s_load per wave instead of 64 identical vector loads per lane.
+  rt::SceneView sv = sv_in;
+  sv.entries = entries_ro;
+  sv.top_level = top_level_ro;
+  sv.spheres = spheres_ro; sv.moving_spheres = msph_ro; sv.rects = rects_ro; sv.triangles = tris_ro;
+  sv.materials = mats_ro; sv.textures = tex_ro; sv.refs = refs_ro;
   extern __shared__ int32_t lds_stack[];
   LdsStack stack;
   stack.base = lds_stack + threadIdx.x;
@@ -800,7 +817,9 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
 #define LAUNCH_PERSISTENT(FEAT)                                                                       \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_persistent<FEAT>), dim3(grid), dim3(TRACE_BLOCK),        \
                      lds_bytes, stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, \
-                     ds->work_counter)
+                     ds->work_counter, ds->view.entries, ds->view.top_level, ds->view.spheres,             \
+                     ds->view.moving_spheres, ds->view.rects, ds->view.triangles, ds->view.materials,      \
+                     ds->view.textures, ds->view.refs)
         if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES); }
         else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH); }
         else { LAUNCH_PERSISTENT(P_ALL); }
