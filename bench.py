@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (marks the run as non-headline)")
     ap.add_argument("--count-spp", type=int, default=32, help="spp of the instrumented counting run (same pixels and seeds)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work (wall seconds) of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work (wall seconds) of the CPU baseline sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on a box with fewer GPUs than ranks (shards gathered through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true")
@@ -206,6 +206,14 @@ def main():
             cpu = {"value": round(width * height * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": "%dx%d at %d spp (same scene, camera, depth, seeds), oracle O1 with %d row-band threads, %.1f s" % (
                        width, height, cpu_spp, cores, dt)}
+            # the README's setting (10 threads, README.md:23), on a smaller sample of the same workload
+            spp10 = int(max(1, min(spp, round(cpu_spp * 10.0 / max(10, cores) * 0.5))))
+            ccfg.samples_per_pixel = spp10
+            t0 = time.perf_counter()
+            orc.o1_render(b.graph_ptr(), world, cam, ccfg, height, threads=10)
+            dt10 = time.perf_counter() - t0
+            cpu["ten_threads"] = {"value": round(width * height * spp10 / dt10 / 1e6, 4), "cores": 10,
+                                  "sample": "%d spp, %.1f s" % (spp10, dt10)}
         out = {
             "metric": "Msamples/s (pixels x spp) on Book-1 final scene" if args.workload in ("c1", "c2", "c5") else "Msamples/s (pixels x spp)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
