@@ -18,11 +18,16 @@ RT_HD Vec3 random_range_vec3(Rng& g, double mn, double mx) {
   double x = rng_range(g, mn, mx), y = rng_range(g, mn, mx), z = rng_range(g, mn, mx);
   return v3(x, y, z);
 }
+// One iteration of random_in_unit_sphere's rejection loop (vec3.rs:288-294): three draws, accept test.
+RT_HD bool sphere_sample_try(Rng& g, Vec3* p) {
+  *p = random_range_vec3(g, -1.0, 1.0);
+  return length_squared(*p) < 1.0;
+}
 // vec3.rs:287-295
 RT_HD Vec3 random_in_unit_sphere(Rng& g) {
   for (;;) {
-    Vec3 p = random_range_vec3(g, -1.0, 1.0);
-    if (length_squared(p) < 1.0) return p;
+    Vec3 p;
+    if (sphere_sample_try(g, &p)) return p;
   }
 }
 // vec3.rs:297-299
@@ -153,27 +158,27 @@ RT_HD Color material_emitted(const SceneView& sv, const FlatMaterial& m, const H
 
 // Material::scatter for all five materials.
 // Lambertian, Metal and Isotropic each begin by drawing one random_in_unit_sphere() sample
-// (hit.rs:1040 via random_unit_vector, hit.rs:1074, hit.rs:1007) and draw nothing else, so the
-// rejection loop is hoisted in front of the material switch: same draws in the same order, but the
-// loop exists once in the kernel and all three materials' lanes iterate it together.
+// (hit.rs:1040 via random_unit_vector, hit.rs:1074, hit.rs:1007) and draw nothing else, so scatter is
+// split in two: (1) does this material want a sphere sample, (2) the rest of scatter given that
+// sample.  material_scatter() glues them in the reference's order; the device may run the rejection
+// loop of (1) elsewhere (its own stage / its own loop) as long as the path's draws keep their order.
+RT_HD bool material_needs_sphere_sample(int32_t kind) {
+  return kind == MAT_LAMBERTIAN || kind == MAT_METAL || kind == MAT_ISOTROPIC;
+}
+
 template <uint32_t F, bool COUNT>
-RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ray& r_in,
-                            const HitRecord& rec, Rng& g, Ray* scattered, Color* attenuation,
-                            TraceCounters* cnt) {
+RT_HD bool material_scatter_with_sample(const SceneView& sv, const FlatMaterial& m, const Ray& r_in,
+                                        const HitRecord& rec, Rng& g, Vec3 sphere_sample, Ray* scattered,
+                                        Color* attenuation, TraceCounters* cnt) {
   if (COUNT) cnt->scatters++;
-  const bool is_lambertian = (F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN;
-  const bool is_metal = (F & F_METAL) && m.kind == MAT_METAL;
-  const bool is_isotropic = (F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC;
-  Vec3 sphere_sample = v3(0, 0, 0);
-  if (is_lambertian || is_metal || is_isotropic) sphere_sample = random_in_unit_sphere(g);
-  if (is_lambertian) {  // hit.rs:1039-1051
+  if ((F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN) {  // hit.rs:1039-1051
     Vec3 scatter_direction = rec.normal + unit(sphere_sample);  // random_unit_vector, vec3.rs:297-299
     if (near_zero(scatter_direction)) scatter_direction = rec.normal;
     *scattered = make_ray(rec.p, scatter_direction, r_in.time);
     *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
     return true;
   }
-  if (is_metal) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
+  if ((F & F_METAL) && m.kind == MAT_METAL) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
     Vec3 reflected = reflect(unit(r_in.direction), rec.normal);
     Vec3 dir = reflected + m.param * sphere_sample;
     *scattered = make_ray(rec.p, dir, r_in.time);
@@ -195,12 +200,21 @@ RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ra
     *attenuation = v3(1, 1, 1);
     return true;
   }
-  if (is_isotropic) {  // hit.rs:1005-1010
+  if ((F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC) {  // hit.rs:1005-1010
     *scattered = make_ray(rec.p, sphere_sample, r_in.time);
     *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
     return true;
   }
   return false;  // MAT_DIFFUSE_LIGHT, hit.rs:1146-1148
+}
+
+template <uint32_t F, bool COUNT>
+RT_HD bool material_scatter(const SceneView& sv, const FlatMaterial& m, const Ray& r_in,
+                            const HitRecord& rec, Rng& g, Ray* scattered, Color* attenuation,
+                            TraceCounters* cnt) {
+  Vec3 sphere_sample = v3(0, 0, 0);
+  if (material_needs_sphere_sample(m.kind)) sphere_sample = random_in_unit_sphere(g);
+  return material_scatter_with_sample<F, COUNT>(sv, m, r_in, rec, g, sphere_sample, scattered, attenuation, cnt);
 }
 
 }  // namespace rt
