@@ -26,6 +26,10 @@
 namespace rtx {
 
 // ------------------------------------------------------------------ device scene
+struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
+  uint32_t n_nodes, n_refs, n_spheres, n_moving;
+};
+
 struct DeviceScene {
   int device = -1;
   std::vector<void*> allocations;
@@ -49,10 +53,19 @@ struct DeviceScene {
   bool vote_diag = false;             // RTX_TRACE_KERNEL=vote_diag: occupancy counters on stderr (never timed)
   unsigned long long* diag = nullptr;
   int vote_blocks_per_cu[2] = {1, 1};
+  bool vote_ring[2] = {false, false}; // k_trace_vote keeps a ring of ready primary rays in LDS (when it costs no occupancy)
   bool single_bvh = false;            // world == one BVH entry -> k_trace_stream applies
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step
+  bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
+  bool lds_ring = false;
+  LdsSceneDims lds_dims = {0, 0, 0, 0};
+  bool force_wq = false;              // RTX_TRACE_KERNEL=wq: workgroup-queue kernel (trace_wq.inc)
+  bool wq_diag = false;               // RTX_TRACE_KERNEL=wq_diag: stage occupancy counters on stderr (never timed)
+  bool wq_ok = false;                 // world fits k_trace_wq's 16-bit work items and LDS budget
+  uint32_t wq_paths = 0, wq_levels = 0, wq_walkers = 12, wq_batch_min = 48;
+  unsigned int* error_word = nullptr;
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -86,6 +99,7 @@ static void free_device_scene(DeviceScene* ds) {
   if (ds->counters) (void)hipFree(ds->counters);
   if (ds->work_counter) (void)hipFree(ds->work_counter);
   if (ds->diag) (void)hipFree(ds->diag);
+  if (ds->error_word) (void)hipFree(ds->error_word);
   for (int i = 0; i < 2; ++i)
     if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
   delete ds;
@@ -404,9 +418,9 @@ __device__ __forceinline__ void walk_node_step(const rt::SceneView& sv, const rt
 }
 // Node step on the f32 culling tree (core/cull32.hpp): cheaper per step (2-cycle f32 issue, 64-B
 // node) and, being conservative, invisible in the result.
-__device__ __forceinline__ void walk_node_step32(const rt::SceneView& sv, const rt::Ray32& q, uint32_t dir_neg,
-                                                 float t_max32, int32_t* cur, LdsStack& stack) {
-  const rt::FlatNode32& n = sv.nodes32[*cur];
+template <class STACK>
+__device__ __forceinline__ void walk_node_step32(const rt::FlatNode32& n, const rt::Ray32& q, uint32_t dir_neg,
+                                                 float t_max32, int32_t* cur, STACK& stack) {
   int first = (int)((dir_neg >> (uint32_t)n.axis) & 1u);
   bool hf = rt::cull32_may_hit(n.lo[first], n.hi[first], q, t_max32);
   bool hs = rt::cull32_may_hit(n.lo[1 - first], n.hi[1 - first], q, t_max32);
@@ -448,7 +462,7 @@ struct VoteWalk {
       unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
       if ((m_node | m_leaf) == 0ull) break;
       if ((uint32_t)__popcll(m_node) * 3u >= (uint32_t)__popcll(m_leaf)) {
-        if (is_node) walk_node_step32(sv, q, dir_neg, t_max32, &cur, stack);
+        if (is_node) walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
       } else {
         if (is_leaf) {
           walk_leaf_step<F>(sv, first_ref, r, t_min, best, &cur, stack);
@@ -463,13 +477,22 @@ struct VoteWalk {
 // DIAG: per-region occupancy counters (diag[2k] = times the wave executed region k, diag[2k+1] = lanes
 // active in it); regions: 0 outer iteration, 1 regenerate, 2 node step, 3 leaf step, 4 shade (hit lanes),
 // 5 shade (all walking lanes).  Diagnostic build only (RTX_TRACE_KERNEL=vote_diag); never timed.
-template <uint32_t F, bool DIAG>
+//
+// RING: primary rays are produced 64 at a time.  Regeneration (Philox seeding, pixel jitter, lens
+// rejection loop, camera ray: ~600 VALU) used to run every outer iteration for just the ~20 lanes
+// whose path had ended.  With RING a wave keeps up to 64 ready primary rays (ray + RNG state + sample
+// index, 76 B each) in its own slice of LDS; a lane whose path ends pops one (10 LDS reads), and only
+// when the ring cannot serve the request does the whole wave run the regeneration code, all lanes at
+// once, to top the ring up.  Which lane traces a sample is invisible in the result.
+#define RING_F64 9  // origin(3) direction(3) time rng.s0 rng.s1
+#define RING_BYTES_PER_WAVE (64u * (RING_F64 * 8u + 4u))
+template <uint32_t F, bool DIAG, bool RING>
 __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
                                                             ShardMap sm, uint32_t s_begin, uint32_t total,
                                                             uint32_t npix, double* __restrict__ samples,
                                                             unsigned int* work_counter,
                                                             unsigned long long* diag, uint32_t leaf_weight,
-                                                            uint32_t walk_threshold) {
+                                                            uint32_t walk_threshold, uint32_t stack_levels) {
   unsigned long long dg[12];
   if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
 #define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
@@ -478,6 +501,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
   stack.base = lds_stack + threadIdx.x;
   stack.n = 0;
   const uint32_t lane = threadIdx.x & 63u;
+  // this wave's ring of ready primary rays: f64 [RING_F64][64], then u32 [64] (sample index)
+  double* const ring_f = (double*)((unsigned char*)(lds_stack + stack_levels * TRACE_BLOCK) +
+                                   (threadIdx.x >> 6) * RING_BYTES_PER_WAVE);
+  uint32_t* const ring_g = (uint32_t*)(ring_f + RING_F64 * 64);
+  uint32_t ring_n = 0;                    // wave-uniform: entries in the ring (a stack)
   const rt::FlatEntry& bvh = sv.entries[sv.top_level[0]];
   const int32_t root = bvh.a;
   const uint32_t first_ref = (uint32_t)bvh.b;
@@ -496,7 +524,61 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
   best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
   for (;;) {
     unsigned long long need_mask = __ballot(!active);
-    if (need_mask != 0ull) {
+    if (RING) {
+      if (need_mask != 0ull) {
+        const uint32_t n_need = (uint32_t)__popcll(need_mask);
+        // top the ring up (at most twice: a chunk boundary can cut the first batch short)
+        for (int rep = 0; rep < 2 && ring_n < n_need && !queue_empty; ++rep) {
+          if (chunk_pos >= chunk_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total) { queue_empty = true; break; }
+            chunk_pos = base;
+            chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
+          }
+          const uint32_t room = 64u - ring_n, avail = chunk_end - chunk_pos;
+          const uint32_t m = room < avail ? room : avail;
+          DIAG_ADD(1, __ballot(lane < m));
+          if (lane < m) {
+            const uint32_t gg = chunk_pos + lane;
+            uint32_t s_local = gg / npix;
+            uint32_t lp = gg - s_local * npix;
+            uint32_t i, j;
+            shard_pixel(sm, lp, &i, &j);
+            rt::PathState fresh;
+            rt::path_begin(rp, i, j, s_begin + s_local, &fresh);
+            const uint32_t slot = ring_n + lane;
+            ring_f[0 * 64 + slot] = fresh.ray.origin.x; ring_f[1 * 64 + slot] = fresh.ray.origin.y;
+            ring_f[2 * 64 + slot] = fresh.ray.origin.z; ring_f[3 * 64 + slot] = fresh.ray.direction.x;
+            ring_f[4 * 64 + slot] = fresh.ray.direction.y; ring_f[5 * 64 + slot] = fresh.ray.direction.z;
+            ring_f[6 * 64 + slot] = fresh.ray.time;
+            ring_f[7 * 64 + slot] = rt::bits_f64(fresh.rng.s0); ring_f[8 * 64 + slot] = rt::bits_f64(fresh.rng.s1);
+            ring_g[slot] = gg;
+          }
+          chunk_pos += m;
+          ring_n += m;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS executes a wave's accesses in order
+        }
+        const uint32_t take = n_need < ring_n ? n_need : ring_n;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+        if (!active && rank < take) {
+          const uint32_t slot = ring_n - 1u - rank;
+          ps.ray = rt::make_ray(rt::v3(ring_f[0 * 64 + slot], ring_f[1 * 64 + slot], ring_f[2 * 64 + slot]),
+                                rt::v3(ring_f[3 * 64 + slot], ring_f[4 * 64 + slot], ring_f[5 * 64 + slot]),
+                                ring_f[6 * 64 + slot]);
+          ps.rng.s0 = rt::f64_bits(ring_f[7 * 64 + slot]); ps.rng.s1 = rt::f64_bits(ring_f[8 * 64 + slot]);
+          ps.product = rt::v3(1, 1, 1);   // path_begin's constants (core/integrator.hpp)
+          ps.output = rt::v3(0, 0, 0);
+          ps.depth = rp.max_depth;
+          g = ring_g[slot];
+          active = true;
+        }
+        ring_n -= take;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    } else if (need_mask != 0ull) {
       if (chunk_pos >= chunk_end && !queue_empty) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
@@ -547,7 +629,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
     // ---- walk: cost-weighted node/leaf vote.  The loop stops as soon as fewer than `walk_threshold`
     // lanes are still walking: the stragglers keep their walk state and continue next round, so the
     // wave never waits for the longest walk of a bounce (all remaining ones once the queue is empty).
-    const uint32_t threshold = queue_empty ? 1u : walk_threshold;
+    const uint32_t threshold = (queue_empty && ring_n == 0u) ? 1u : walk_threshold;
     for (;;) {
       bool walking = midwalk && cur != WALK_DONE;
       bool is_leaf = walking && cur < 0;
@@ -556,7 +638,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
       if ((uint32_t)__popcll(m_node | m_leaf) < threshold) break;
       if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
         DIAG_ADD(2, m_node);
-        if (is_node) walk_node_step32(sv, q, dir_neg, t_max32, &cur, stack);
+        if (is_node) walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
       } else {
         DIAG_ADD(3, m_leaf);
         if (is_leaf) {
@@ -586,6 +668,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
   }
 #undef DIAG_ADD
 }
+
+#include "trace_wq.inc"
+#include "trace_lds.inc"
 
 // One lane per pixel; samples of the pass are added in ascending sample index.
 __global__ __launch_bounds__(256) void k_reduce_samples(const double* __restrict__ samples,
@@ -771,21 +856,66 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           else { LAUNCH_SIMPLE(P_ALL); }
         }
 #undef LAUNCH_SIMPLE
+      } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream) {
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring, ds->lds_dims);
+        uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
+        uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
+#define LAUNCH_LDS(RINGF)                                                                              \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<P_SPHERES, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
+                     ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
+                     ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, ds->lds_dims)
+        if (ds->lds_ring) { LAUNCH_LDS(true); } else { LAUNCH_LDS(false); }
+#undef LAUNCH_LDS
+      } else if (ds->force_wq && ds->wq_ok && preset == 0) {
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        if (!ds->error_word) HIP_TRY(hipMalloc((void**)&ds->error_word, sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(ds->error_word, 0, sizeof(unsigned int), stream));
+        const WqLayout L = wq_layout(ds->wq_paths, ds->wq_levels);
+        uint64_t want = ((uint64_t)total + ds->wq_paths - 1) / ds->wq_paths;
+        uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
+        if (ds->wq_diag) {
+          if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
+          HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_wq<P_SPHERES, true>), dim3(grid), dim3(WQ_THREADS), L.total, stream,
+                             ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
+                             ds->error_word, ds->wq_paths, ds->wq_levels, ds->wq_walkers, ds->wq_batch_min, ds->diag);
+          HIP_TRY(hipStreamSynchronize(stream));
+          unsigned long long h[24];
+          HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
+          const char* tnames[6] = {"gen", "walk(total)", "walk:refill", "shade", "idle", "kernel"};
+          for (int k = 0; k < 6; ++k)
+            fprintf(stderr, "[wq_diag] wave-time %-12s %6.2f %%\n", tnames[k], h[16 + 5] ? 100.0 * (double)h[16 + k] / (double)h[16 + 5] : 0.0);
+          const char* names[8] = {"node_step", "leaf_step", "refill", "shade", "gen", "idle_poll", "walk_loop", "short_refill"};
+          for (int k = 0; k < 8; ++k)
+            fprintf(stderr, "[wq_diag] %-12s executions %llu lanes %llu mean %.2f\n", names[k], h[2 * k], h[2 * k + 1],
+                    h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+        } else {
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_wq<P_SPHERES, false>), dim3(grid), dim3(WQ_THREADS), L.total, stream,
+                             ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
+                             ds->error_word, ds->wq_paths, ds->wq_levels, ds->wq_walkers, ds->wq_batch_min, (unsigned long long*)nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        unsigned int err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, ds->error_word, sizeof(err), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
       } else if (ds->single_bvh && preset < 2 && !ds->force_persistent && !ds->force_stream) {
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->vote_blocks_per_cu[preset];
-        uint32_t grid = (uint32_t)(want < resident ? want : resident);
-#define LAUNCH_VOTE(FEAT)                                                                             \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, \
+        uint32_t grid = 0;
+        const bool ring = ds->vote_ring[preset];
+        const size_t vote_lds = lds_bytes + (ring ? (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE : 0);
+        grid = (uint32_t)(want < resident ? want : resident);
+#define LAUNCH_VOTE(FEAT, DIAGF, RINGF, DIAGP)                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
-                     ds->work_counter, (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold)
+                     ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels)
         if (ds->vote_diag && preset == 0) {
-          if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 12 * sizeof(unsigned long long)));
+          if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_SPHERES, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes,
-                             stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,
-                             ds->work_counter, ds->diag, ds->leaf_weight, ds->walk_threshold);
+          if (ring) { LAUNCH_VOTE(P_SPHERES, true, true, ds->diag); } else { LAUNCH_VOTE(P_SPHERES, true, false, ds->diag); }
           HIP_TRY(hipStreamSynchronize(stream));
           unsigned long long h[12];
           HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
@@ -794,8 +924,8 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
             fprintf(stderr, "[vote_diag] %-10s executions %llu lanes %llu mean lanes %.2f\n", names[k], h[2 * k], h[2 * k + 1],
                     h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
         }
-        else if (preset == 0) { LAUNCH_VOTE(P_SPHERES); }
-        else { LAUNCH_VOTE(P_MESH); }
+        else if (preset == 0) { if (ring) { LAUNCH_VOTE(P_SPHERES, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_SPHERES, false, false, (unsigned long long*)nullptr); } }
+        else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
       } else if (ds->single_bvh && preset < 2 && ds->force_stream) {
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -909,9 +1039,93 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     ds->force_stream = (k && strcmp(k, "stream") == 0);
     ds->vote_diag = (k && strcmp(k, "vote_diag") == 0);
     ds->force_vote = ds->vote_diag || (k && strcmp(k, "vote") == 0);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[0] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_vote<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->vote_blocks_per_cu[1] = nb;
+    {
+      const size_t lds_ring = lds + (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE;
+      int nb0 = 0, nb1 = 0;
+      const char* rg = getenv("RTX_RING");
+      // preset 0
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_SPHERES, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_SPHERES, false, true>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
+      ds->vote_ring[0] = nb1 > 0 && nb1 >= nb0 && lds_ring <= 64 * 1024;
+      if (rg && nb1 > 0 && lds_ring <= 64 * 1024) ds->vote_ring[0] = atoi(rg) != 0;
+      nb = ds->vote_ring[0] ? nb1 : nb0;
+      if (nb > 0) ds->vote_blocks_per_cu[0] = nb;
+      // preset 1
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_MESH, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_MESH, false, true>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
+      ds->vote_ring[1] = nb1 > 0 && nb1 >= nb0 && lds_ring <= 64 * 1024;
+      if (rg && nb1 > 0 && lds_ring <= 64 * 1024) ds->vote_ring[1] = atoi(rg) != 0;
+      nb = ds->vote_ring[1] ? nb1 : nb0;
+      if (nb > 0) ds->vote_blocks_per_cu[1] = nb;
+    }
     ds->single_bvh = fs.top_level.size() == 1 && fs.entries[fs.top_level[0]].kind == rt::ENTRY_BVH;
+    if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes32.size() <= LDSK_MAX_NODES) {
+      uint32_t max_count = 0, max_end = 0;
+      for (const rt::FlatNode& nd : fs.nodes)
+        for (int ch = 0; ch < 2; ++ch)
+          if (nd.child[ch] < 0) {
+            max_count = std::max(max_count, rt::leaf_count(nd.child[ch]));
+            max_end = std::max(max_end, rt::leaf_first(nd.child[ch]) + rt::leaf_count(nd.child[ch]));
+          }
+      int lds_max = 0;
+      (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
+      if (lds_max > 160 * 1024) lds_max = 160 * 1024;
+      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size()};
+      const uint32_t levels = (uint32_t)fs.max_stack + 1u;
+      const char* sl = getenv("RTX_SCENE_LDS");
+      const char* rg = getenv("RTX_RING");
+      const bool want_ring = !(rg && atoi(rg) == 0);
+      if (max_count <= 4 && max_end <= LDSK_MAX_SLOTS && !(sl && atoi(sl) == 0) && lds_max > 0) {
+        if (want_ring && ldsk_layout(levels, true, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = true; }
+        else if (ldsk_layout(levels, false, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
+      }
+      if (ds->lds_ok) {
+        const int bytes = (int)ldsk_layout(levels, ds->lds_ring, ds->lds_dims).total;
+        hipError_t ae = ds->lds_ring
+            ? hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+            : hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
+      }
+      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring %d, %u B of LDS)\n", ds->lds_ok ? "on" : "off", (int)ds->lds_ring,
+                      ldsk_layout(levels, ds->lds_ring, ds->lds_dims).total);
+    }
+    ds->wq_diag = (k && strcmp(k, "wq_diag") == 0);
+    ds->force_wq = ds->wq_diag || (k && strcmp(k, "wq") == 0);
+    if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes.size() <= WQ_MAX_NODES) {
+      const rt::FlatEntry& be = fs.entries[fs.top_level[0]];
+      uint32_t max_count = 0, max_end = 0;
+      for (const rt::FlatNode& nd : fs.nodes)
+        for (int ch = 0; ch < 2; ++ch)
+          if (nd.child[ch] < 0) {
+            max_count = std::max(max_count, rt::leaf_count(nd.child[ch]));
+            max_end = std::max(max_end, rt::leaf_first(nd.child[ch]) + rt::leaf_count(nd.child[ch]));
+          }
+      int lds_max = 0;
+      (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
+      if (lds_max > 160 * 1024) lds_max = 160 * 1024;
+      ds->wq_levels = (uint32_t)fs.max_stack + 1u;
+      ds->wq_paths = lds_max > 0 ? wq_paths_for(ds->wq_levels, (uint32_t)lds_max) : 0u;
+      const char* wp = getenv("RTX_WQ_PATHS");
+      if (wp && atoi(wp) >= 64 && (uint32_t)atoi(wp) <= ds->wq_paths) ds->wq_paths = (uint32_t)atoi(wp) & ~63u;
+      const char* ww = getenv("RTX_WQ_WALKERS");
+      ds->wq_walkers = ds->wq_paths >= 192 ? (ds->wq_paths - 128) / 64 : 1;
+      if (ww && atoi(ww) >= 1 && atoi(ww) <= 16) ds->wq_walkers = (uint32_t)atoi(ww);
+      (void)be;
+      const char* wb = getenv("RTX_WQ_BATCH");
+      if (wb && atoi(wb) >= 1 && atoi(wb) <= 64) ds->wq_batch_min = (uint32_t)atoi(wb);
+      ds->wq_ok = ds->wq_paths > 0 && max_count <= 4 && max_end <= WQ_MAX_SLOTS;
+      if (ds->wq_ok && ds->force_wq) {
+        const WqLayout L = wq_layout(ds->wq_paths, ds->wq_levels);
+        if (hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess) {
+          (void)hipGetLastError();
+          ds->wq_ok = false;
+        }
+      }
+    }
+    if (ds->force_wq)
+      fprintf(stderr, "[rtx] RTX_TRACE_KERNEL=wq: %s (paths %u, stack levels %u, walkers %u)\n",
+              ds->wq_ok ? "applies" : "does NOT apply to this world, default kernel runs", ds->wq_paths, ds->wq_levels, ds->wq_walkers);
     const char* lw = getenv("RTX_LEAF_WEIGHT");
     if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
     const char* wt = getenv("RTX_WALK_THRESHOLD");

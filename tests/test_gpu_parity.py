@@ -76,6 +76,32 @@ def test_scheduling_independence(rtsr, monkeypatch):
     assert np.array_equal(base.accum, multi.accum)
 
 
+# Every trace-kernel variant the library can be switched to must produce the oracle's accumulators:
+# which wave, lane or kernel traces a sample is a scheduling matter and must be invisible in the result.
+VARIANTS = [
+    {"RTX_RING": "0"},                      # voting kernel, regeneration per lane (no LDS ring of primary rays)
+    {"RTX_RING": "1"},                      # voting kernel + ring (default where LDS allows)
+    {"RTX_TRACE_KERNEL": "persistent"},
+    {"RTX_TRACE_KERNEL": "stream"},
+    {"RTX_TRACE_KERNEL": "simple"},
+    {"RTX_TRACE_KERNEL": "wq"},             # workgroup LDS path queues (experimental)
+    {"RTX_WALK_THRESHOLD": "1", "RTX_LEAF_WEIGHT": "1"},
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=["-".join("%s=%s" % kv for kv in v.items()) for v in VARIANTS])
+@pytest.mark.parametrize("sid,width,aspect,spp", [(100, 144, 1.5, 12), (13, 128, 16.0 / 9.0, 6)])
+def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, aspect, spp):
+    b, world, cam, cfg, flat = _setup(rtsr, sid, width, aspect, spp, {}, seed=11)
+    h = rtsr.image_height(cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    screen = flat.upload().render(cam, cfg)
+    assert np.array_equal(screen.accum, ref_accum)
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+
+
 def test_device_arithmetic_matches_host(rtsr, orc):
     rng = np.random.default_rng(5)
     n = 200000
