@@ -46,6 +46,22 @@ def algorithmic_bytes(c):
             c["perlin_calls"] * S_PERLIN + c["samples"] * S_OUT)
 
 
+def usable_cores():
+    """CPUs this process may use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return cores
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,11 +125,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     trace_ms = []
+    kernel_used = []
 
     def step(record):
         stats = scene.render_device(cam, cfg, shard=shard, d_rgb8=d_rgb8.data_ptr(), stream=stream, want_stats=True)
         if record:
             trace_ms.append((stats.trace_ms, stats.trace_launches))
+            kernel_used.append(stats.trace_kernel)
         if world_size > 1:
             if host_stage is not None:
                 host_stage.copy_(d_rgb8)  # gloo rehearsal path only
@@ -176,7 +194,7 @@ def main():
                         pmc = rec.get("hbm_bytes_per_launch")
                 except Exception:
                     pmc = None
-            roofline = {"bound": "hbm", "kernel": "k_trace_vote" if args.workload in ("c1", "c2", "c5", "head") else "k_trace_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": rtsr.trace_kernel_name(kernel_used[-1]) if kernel_used else "?", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc,
                         "bytes_per_sample": round(bytes_per_sample, 1), "kernel_ms": round(mean_trace_ms, 3),
                         "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),
@@ -188,11 +206,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py as orc
             ccfg = rtsr.RtxConfig.from_buffer_copy(cfg)
-            cores = os.cpu_count() or 1
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            cores = usable_cores()
             # calibrate on 1 spp, then size the sample to ~args.cpu_seconds of wall time (bounded by the full spp)
             ccfg.samples_per_pixel = 1
             t0 = time.perf_counter()

@@ -180,7 +180,19 @@ typedef struct RtxRenderStats {
   double trace_ms, reduce_ms, tonemap_ms; /* device time of the kernels of this render (HIP events) */
   int32_t trace_launches, passes;
   uint64_t sample_buffer_bytes;
+  int32_t trace_kernel; /* which trace kernel the launcher chose: RTX_KERNEL_* (rtx_trace_kernel_name) */
+  int32_t reserved;
 } RtxRenderStats;
+/* Trace kernels (all produce identical results; the launcher picks by world shape and LDS budget). */
+enum {
+  RTX_KERNEL_SIMPLE = 0,     /* grid-stride, one whole path per thread (also the counting kernel) */
+  RTX_KERNEL_PERSISTENT = 1, /* persistent waves + path regeneration; any world */
+  RTX_KERNEL_STREAM = 2,     /* A/B only */
+  RTX_KERNEL_VOTE = 3,       /* worlds that are one BVH: node/leaf voting walk, f32 culling, carry-over */
+  RTX_KERNEL_LDS = 4,        /* RTX_KERNEL_VOTE with the geometry resident in LDS (sphere worlds that fit) */
+  RTX_KERNEL_WQ = 5          /* experimental: workgroup-level path queues in LDS */
+};
+const char* rtx_trace_kernel_name(int32_t kernel);
 /* Blocking; host output buffers.  Renders the whole image on the current device. */
 rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out);
 

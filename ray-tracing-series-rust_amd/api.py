@@ -70,7 +70,8 @@ class RtxRenderStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "box_tests", "sphere_tests", "moving_sphere_tests",
                                           "rect_tests", "triangle_tests", "scatters", "texels", "perlin_calls")] + \
                [("trace_ms", C.c_double), ("reduce_ms", C.c_double), ("tonemap_ms", C.c_double),
-                ("trace_launches", C.c_int32), ("passes", C.c_int32), ("sample_buffer_bytes", C.c_uint64)]
+                ("trace_launches", C.c_int32), ("passes", C.c_int32), ("sample_buffer_bytes", C.c_uint64),
+                ("trace_kernel", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RtxShard(C.Structure):
@@ -85,6 +86,7 @@ _H = C.c_int32
 ABI = {
     "rtx_abi_version": (C.c_int32, []),
     "rtx_last_error": (C.c_char_p, []),
+    "rtx_trace_kernel_name": (C.c_char_p, [C.c_int32]),
     "rtx_builder_create": (C.c_int32, [C.c_uint64, C.POINTER(_VP)]),
     "rtx_builder_destroy": (None, [_VP]),
     "rtx_builder_random": (C.c_double, [_VP]),
@@ -407,6 +409,10 @@ class Scene:
         stats = RtxRenderStats()
         _check(lib.rtx_render_count(self._p, C.byref(cam), C.byref(cfg), C.byref(sh) if sh else None, C.byref(stats)))
         return stats
+
+
+def trace_kernel_name(kernel):
+    return (lib.rtx_trace_kernel_name(kernel) or b"").decode()
 
 
 def device_math(fn, x, y=None):

@@ -63,4 +63,38 @@ RT_HD bool cull32_may_hit(const float* lo, const float* hi, const Ray32& q, floa
   return !(tn > tf);
 }
 
+// Both children of a node at once.  Same arithmetic as two cull32_may_hit calls; on the device the twelve plane
+// fmas are written as four 2-wide ones (x and y of a plane set) plus four scalar ones for z, so that the pairs
+// issue as v_pk_fma_f32 -- an fma gives the same value whichever instruction carries it.
+RT_HD void cull32_may_hit2(const float* lo0, const float* hi0, const float* lo1, const float* hi1, const Ray32& q,
+                           float t_max32, bool* hit0, bool* hit1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 ixy = {q.ix, q.iy}, oxy = {-q.oix, -q.oiy};
+  const float noz = -q.oiz;
+  // x and y of one plane set are adjacent in memory (they arrive as one register pair): pack those
+  const f2 a0 = __builtin_elementwise_fma((f2){lo0[0], lo0[1]}, ixy, oxy), b0 = __builtin_elementwise_fma((f2){hi0[0], hi0[1]}, ixy, oxy);
+  const f2 a1 = __builtin_elementwise_fma((f2){lo1[0], lo1[1]}, ixy, oxy), b1 = __builtin_elementwise_fma((f2){hi1[0], hi1[1]}, ixy, oxy);
+  const float az0 = __builtin_fmaf(lo0[2], q.iz, noz), bz0 = __builtin_fmaf(hi0[2], q.iz, noz);
+  const float az1 = __builtin_fmaf(lo1[2], q.iz, noz), bz1 = __builtin_fmaf(hi1[2], q.iz, noz);
+  float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0.x, b0.x), __builtin_fminf(a0.y, b0.y)),
+                              __builtin_fmaxf(__builtin_fminf(az0, bz0), q.t_min));
+  float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0.x, b0.x), __builtin_fmaxf(a0.y, b0.y)),
+                              __builtin_fminf(__builtin_fmaxf(az0, bz0), t_max32));
+  float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a1.x, b1.x), __builtin_fminf(a1.y, b1.y)),
+                              __builtin_fmaxf(__builtin_fminf(az1, bz1), q.t_min));
+  float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1.x, b1.x), __builtin_fmaxf(a1.y, b1.y)),
+                              __builtin_fminf(__builtin_fmaxf(az1, bz1), t_max32));
+  tn0 = __builtin_fmaf(-__builtin_fabsf(tn0), 0x1.0p-22f, tn0) - q.err;
+  tf0 = __builtin_fmaf(__builtin_fabsf(tf0), 0x1.0p-22f, tf0) + q.err;
+  tn1 = __builtin_fmaf(-__builtin_fabsf(tn1), 0x1.0p-22f, tn1) - q.err;
+  tf1 = __builtin_fmaf(__builtin_fabsf(tf1), 0x1.0p-22f, tf1) + q.err;
+  *hit0 = !(tn0 > tf0);
+  *hit1 = !(tn1 > tf1);
+#else
+  *hit0 = cull32_may_hit(lo0, hi0, q, t_max32);
+  *hit1 = cull32_may_hit(lo1, hi1, q, t_max32);
+#endif
+}
+
 }  // namespace rt

@@ -46,7 +46,22 @@ struct Rng {
   uint64_t s0, s1;
 };
 
-RT_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+// 0 < k < 64.  On the device a 64-bit rotate is two v_alignbit_b32 (the generic shift/shift/or form costs four
+// instructions there); same value either way.
+RT_HD uint64_t rotl64(uint64_t x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 v = __builtin_bit_cast(u32x2, x);  // v.x = low half
+  if (k >= 32) { v = v.yx; k -= 32; }
+  if (k == 0) return __builtin_bit_cast(uint64_t, v);
+  u32x2 r;
+  r.y = __builtin_amdgcn_alignbit(v.y, v.x, (uint32_t)(32 - k));  // (hi:lo) >> (32-k) = hi << k | lo >> (32-k)
+  r.x = __builtin_amdgcn_alignbit(v.x, v.y, (uint32_t)(32 - k));
+  return __builtin_bit_cast(uint64_t, r);
+#else
+  return (x << k) | (x >> (64 - k));
+#endif
+}
 
 RT_HD Rng rng_for_sample(uint64_t seed, uint64_t pixel_index, uint32_t sample) {
   uint32_t c[4];

@@ -27,6 +27,17 @@ extern "C" {
 
 int32_t rtx_abi_version(void) { return RTX_ABI_VERSION; }
 const char* rtx_last_error(void) { return g_last_error.c_str(); }
+const char* rtx_trace_kernel_name(int32_t kernel) {
+  switch (kernel) {
+    case RTX_KERNEL_SIMPLE: return "k_trace_simple";
+    case RTX_KERNEL_PERSISTENT: return "k_trace_persistent";
+    case RTX_KERNEL_STREAM: return "k_trace_stream";
+    case RTX_KERNEL_VOTE: return "k_trace_vote";
+    case RTX_KERNEL_LDS: return "k_trace_lds";
+    case RTX_KERNEL_WQ: return "k_trace_wq";
+    default: return "?";
+  }
+}
 
 rtx_status rtx_builder_create(uint64_t scene_seed, rtx_builder** out) {
   if (!out) { set_error("rtx_builder_create: NULL out"); return RTX_EINVAL; }

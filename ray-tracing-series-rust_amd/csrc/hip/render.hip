@@ -105,6 +105,9 @@ static void free_device_scene(DeviceScene* ds) {
   delete ds;
 }
 
+// 64-bit lane mask of a predicate, straight from the compare (HIP's __ballot(int) first materialises 0/1 in a VGPR).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // ------------------------------------------------------------------ pixel enumeration
 // Local pixel lp of a shard -> image (column i, row j).  Rows of a shard are the rows j with
 // (j / block_rows) % shard_count == shard_index, compacted in ascending j.
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView 
   uint32_t g = 0;
   rt::PathState ps;
   for (;;) {
-    unsigned long long need_mask = __ballot(!active);
+    unsigned long long need_mask = wave_ballot(!active);
     if (need_mask != 0ull) {
       if (chunk_pos >= chunk_end && !queue_empty) {
         uint32_t base = 0;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView 
         chunk_pos += (n_need < avail) ? n_need : avail;
       }
     }
-    if (__ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
+    if (wave_ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
     if (active) {
       if (rt::path_step<F, false, LdsStack, VoteWalk>(sv, rp, &ps, stack, nullptr)) {
         double* o = samples + 3 * (size_t)g;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stream(rt::SceneView sv, 
     }
     // ---- phase 1b: regenerate (wave-cooperative; executed by the whole wave)
     {
-      unsigned long long need_mask = __ballot(stage == STAGE_NEED);
+      unsigned long long need_mask = wave_ballot(stage == STAGE_NEED);
       if (need_mask != 0ull) {
         if (chunk_pos >= chunk_end && !queue_empty) {
           uint32_t base = 0;
@@ -370,9 +373,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stream(rt::SceneView sv, 
       }
     }
     // ---- exit: nothing walking, nothing to shade, queue drained
-    unsigned long long walk_mask = __ballot(stage == STAGE_WALK);
+    unsigned long long walk_mask = wave_ballot(stage == STAGE_WALK);
     if (walk_mask == 0ull) {
-      if (queue_empty && __ballot(stage != STAGE_NEED) == 0ull) break;
+      if (queue_empty && wave_ballot(stage != STAGE_NEED) == 0ull) break;
       continue;  // lanes whose path ended in 1c: go regenerate
     }
     // ---- phase 2: node steps while enough lanes walk
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stream(rt::SceneView sv, 
           node = -1;  // the next ray of this lane starts a new bounce
         }
       }
-      walk_mask = __ballot(stage == STAGE_WALK);
+      walk_mask = wave_ballot(stage == STAGE_WALK);
     } while ((uint32_t)__popcll(walk_mask) >= threshold);
   }
 }
@@ -422,8 +425,8 @@ template <class STACK>
 __device__ __forceinline__ void walk_node_step32(const rt::FlatNode32& n, const rt::Ray32& q, uint32_t dir_neg,
                                                  float t_max32, int32_t* cur, STACK& stack) {
   int first = (int)((dir_neg >> (uint32_t)n.axis) & 1u);
-  bool hf = rt::cull32_may_hit(n.lo[first], n.hi[first], q, t_max32);
-  bool hs = rt::cull32_may_hit(n.lo[1 - first], n.hi[1 - first], q, t_max32);
+  bool hf, hs;
+  rt::cull32_may_hit2(n.lo[first], n.hi[first], n.lo[1 - first], n.hi[1 - first], q, t_max32, &hf, &hs);
   int32_t cf = n.child[first], cs = n.child[1 - first];
   if (hf) {
     *cur = cf;
@@ -459,7 +462,7 @@ struct VoteWalk {
     for (;;) {
       bool is_leaf = cur < 0;
       bool is_node = !is_leaf && cur != WALK_DONE;
-      unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
+      unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
       if ((m_node | m_leaf) == 0ull) break;
       if ((uint32_t)__popcll(m_node) * 3u >= (uint32_t)__popcll(m_leaf)) {
         if (is_node) walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
   rt::Closest best;
   best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
   for (;;) {
-    unsigned long long need_mask = __ballot(!active);
+    unsigned long long need_mask = wave_ballot(!active);
     if (RING) {
       if (need_mask != 0ull) {
         const uint32_t n_need = (uint32_t)__popcll(need_mask);
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
           }
           const uint32_t room = 64u - ring_n, avail = chunk_end - chunk_pos;
           const uint32_t m = room < avail ? room : avail;
-          DIAG_ADD(1, __ballot(lane < m));
+          DIAG_ADD(1, wave_ballot(lane < m));
           if (lane < m) {
             const uint32_t gg = chunk_pos + lane;
             uint32_t s_local = gg / npix;
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
         uint32_t n_need = (uint32_t)__popcll(need_mask);
         uint32_t avail = chunk_end - chunk_pos;
-        DIAG_ADD(1, __ballot(!active && rank < avail));
+        DIAG_ADD(1, wave_ballot(!active && rank < avail));
         if (!active && rank < avail) {
           g = chunk_pos + rank;
           uint32_t s_local = g / npix;
@@ -608,8 +611,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
         chunk_pos += (n_need < avail) ? n_need : avail;
       }
     }
-    if (__ballot(active) == 0ull) break;
-    DIAG_ADD(0, __ballot(active));
+    if (wave_ballot(active) == 0ull) break;
+    DIAG_ADD(0, wave_ballot(active));
     // ---- begin a bounce for every lane that is not in the middle of a carried-over walk
     if (active && !midwalk) {
       if (rt::path_bounce_begin(&ps)) {
@@ -631,10 +634,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
     // wave never waits for the longest walk of a bounce (all remaining ones once the queue is empty).
     const uint32_t threshold = (queue_empty && ring_n == 0u) ? 1u : walk_threshold;
     for (;;) {
-      bool walking = midwalk && cur != WALK_DONE;
-      bool is_leaf = walking && cur < 0;
-      bool is_node = walking && cur >= 0;
-      unsigned long long m_node = __ballot(is_node), m_leaf = __ballot(is_leaf);
+      // cur == WALK_DONE whenever a lane is not in a walk, so the item alone tells the lane's state
+      bool is_leaf = cur < 0;
+      bool is_node = (uint32_t)cur < (uint32_t)WALK_DONE;
+      unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
       if ((uint32_t)__popcll(m_node | m_leaf) < threshold) break;
       if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
         DIAG_ADD(2, m_node);
@@ -649,8 +652,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
     }
     // ---- shade the lanes whose walk is complete
     const bool finished = midwalk && cur == WALK_DONE;
-    DIAG_ADD(4, __ballot(finished && best.hit));
-    DIAG_ADD(5, __ballot(finished));
+    DIAG_ADD(4, wave_ballot(finished && best.hit));
+    DIAG_ADD(5, wave_ballot(finished));
     if (finished) {
       midwalk = false;
       rt::HitRecord rec;
@@ -837,12 +840,14 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
 
   float trace_ms = 0.f;
   int passes = 0;
+  int32_t kernel_used = RTX_KERNEL_SIMPLE;
   if (npix > 0) {
     for (uint32_t s_begin = 0; s_begin < spp; s_begin += spp_pass, ++passes) {
       uint32_t s_count = spp - s_begin < spp_pass ? spp - s_begin : spp_pass;
       uint32_t total = (uint32_t)((uint64_t)s_count * npix);
       if (stats) HIP_TRY(hipEventRecord(ds->ev[0], stream));
       if (use_simple) {
+        kernel_used = RTX_KERNEL_SIMPLE;
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu * 8 ? want : (uint64_t)ds->n_cu * 8);
 #define LAUNCH_SIMPLE(FEAT)                                                                          \
@@ -857,6 +862,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         }
 #undef LAUNCH_SIMPLE
       } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream) {
+        kernel_used = RTX_KERNEL_LDS;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring, ds->lds_dims);
         uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
@@ -868,6 +874,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         if (ds->lds_ring) { LAUNCH_LDS(true); } else { LAUNCH_LDS(false); }
 #undef LAUNCH_LDS
       } else if (ds->force_wq && ds->wq_ok && preset == 0) {
+        kernel_used = RTX_KERNEL_WQ;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         if (!ds->error_word) HIP_TRY(hipMalloc((void**)&ds->error_word, sizeof(unsigned int)));
         HIP_TRY(hipMemsetAsync(ds->error_word, 0, sizeof(unsigned int), stream));
@@ -901,6 +908,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         HIP_TRY(hipStreamSynchronize(stream));
         if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
       } else if (ds->single_bvh && preset < 2 && !ds->force_persistent && !ds->force_stream) {
+        kernel_used = RTX_KERNEL_VOTE;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->vote_blocks_per_cu[preset];
@@ -928,6 +936,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
       } else if (ds->single_bvh && preset < 2 && ds->force_stream) {
+        kernel_used = RTX_KERNEL_STREAM;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->stream_blocks_per_cu[preset];
@@ -940,6 +949,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         else { LAUNCH_STREAM(P_MESH); }
 #undef LAUNCH_STREAM
       } else {
+        kernel_used = RTX_KERNEL_PERSISTENT;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->blocks_per_cu[preset];
@@ -979,6 +989,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
     stats->trace_ms = trace_ms;
     stats->trace_launches = passes;
     stats->passes = passes;
+    stats->trace_kernel = kernel_used;
     stats->sample_buffer_bytes = need_samples;
     if (COUNT) {
       rt::TraceCounters c;
