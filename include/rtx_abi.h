@@ -143,7 +143,7 @@ rtx_status rtx_get_world_cam(rtx_builder* b, int32_t scene_id, const RtxSceneOpt
 
 /* ---- flatten + upload ------------------------------------------------------------------ */
 typedef struct RtxBuildOptions {
-  int32_t max_leaf;      /* primitives per BVH leaf, 1..8; 0 = default */
+  int32_t max_leaf;      /* primitives per BVH leaf, 1..8; 0 = default (1; 2 for BVHs holding triangles) */
   int32_t sah_bins;      /* 0 = default */
   int32_t reference_bvh; /* 1: build BVHs with the reference's rule (bvh.rs:14-83) instead of SAH: same image,
                             different traversal statistics (A/B switch) */

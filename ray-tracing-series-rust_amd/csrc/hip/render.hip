@@ -57,7 +57,7 @@ struct DeviceScene {
   bool single_bvh = false;            // world == one BVH entry -> k_trace_stream applies
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
-  uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step
+  uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
   LdsSceneDims lds_dims = {0, 0, 0, 0};
@@ -1137,6 +1137,15 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     if (ds->force_wq)
       fprintf(stderr, "[rtx] RTX_TRACE_KERNEL=wq: %s (paths %u, stack levels %u, walkers %u)\n",
               ds->wq_ok ? "applies" : "does NOT apply to this world, default kernel runs", ds->wq_paths, ds->wq_levels, ds->wq_walkers);
+    // a leaf step costs about (primitives per leaf) x 1.3 node steps for spheres: vote weight 1 for single-primitive
+    // leaves, 3 otherwise (measured on C2 / HEAD / C4)
+    {
+      uint32_t max_count = 1;
+      for (const rt::FlatNode& nd : fs.nodes)
+        for (int ch = 0; ch < 2; ++ch)
+          if (nd.child[ch] < 0) max_count = std::max(max_count, rt::leaf_count(nd.child[ch]));
+      ds->leaf_weight = max_count <= 1 ? 1u : 3u;
+    }
     const char* lw = getenv("RTX_LEAF_WEIGHT");
     if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
     const char* wt = getenv("RTX_WALK_THRESHOLD");

@@ -55,7 +55,7 @@ struct FlatScene {
 };
 
 struct BuildOptions {
-  int max_leaf = 2;   // primitives per BVH leaf (1..8)
+  int max_leaf = 0;   // primitives per BVH leaf (1..8); 0 = per BVH: 2 when it holds triangles, else 1 (measured)
   int sah_bins = 32;
   // 1: build every BVH with the REFERENCE's rule instead of SAH (bvh.rs:14-83: random axis in {x, y},
   // stable sort by the time-(0,0) box minimum, median split, one object per leaf, a span of one stored

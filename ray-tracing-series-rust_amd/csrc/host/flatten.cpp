@@ -204,7 +204,15 @@ struct Flattener {
         for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], 0.0, 0.0, &sort_boxes[6 * i]);
         root = build_bvh_reference(boxes, sort_boxes, opt.bvh_seed + (uint64_t)out.n_bvh, &out.nodes, &order, &depth);
       } else {
-        root = build_bvh(boxes, opt, &out.nodes, &order, &depth, &out.sah_cost);
+        // Leaf size: a sphere or rectangle test costs several box tests, so giving every such primitive its own
+        // (tight) box pays; triangle meshes are deep and their boxes loose, two per leaf measured best.
+        BuildOptions bo = opt;
+        if (bo.max_leaf <= 0) {
+          bool has_tri = false;
+          for (rt::PrimRef r : refs) has_tri |= rt::primref_type(r) == rt::PRIM_TRIANGLE;
+          bo.max_leaf = has_tri ? 2 : 1;
+        }
+        root = build_bvh(boxes, bo, &out.nodes, &order, &depth, &out.sah_cost);
       }
       rt::FlatEntry e = blank_entry(rt::ENTRY_BVH);
       e.a = root;
