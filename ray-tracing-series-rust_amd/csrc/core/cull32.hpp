@@ -6,12 +6,16 @@
 // and so is the closest hit (with its tie rule).  This header provides such a test in f32:
 //
 //   * child boxes are rounded outward to f32 on the host (lo down, hi up);
-//   * the ray is rounded to f32 once per bounce: o32 = fl(o), i32 = fl(1/d), oi = fl(o32*i32);
+//   * the ray is rounded to f32 once per bounce: o32 = fl(o), i32 ~ 1/d, oi = fl(o32*i32).  On the device
+//     i32 = v_rcp_f32(fl(d)) (1 ulp; an f64 division here cost 45 VALU per bounce), on the host fl(1/d): with
+//     u = 2^-24, i32 = (1/d)(1 + e1), |e1| <= 3u in the worse (device) case;
 //   * per axis t = fma(plane, i32, -oi); the slab interval is [min, max] of the two planes;
-//   * first-order error of each t against the real-arithmetic value:
-//         |t - T| <= 2^-24 * (2|t| + 4|oi|)          (rounding of o, 1/d, the product and the fma)
-//     so the interval is widened by |t| * 2^-22 + E with E = 2^-21 * max_axis |oi|.  Because
-//     f(t) = t - |t| eps is monotone the widening is applied once, after the max / min over axes;
+//   * first-order error of each t against the real-arithmetic value T = (plane - o)/d:
+//         t - T = T e1 - (o/d)(e2 + e3) + t e4     (e2: rounding of o, e3: of the product oi, e4: of the fma)
+//         |t - T| <= 4u |t| + 2u |oi|
+//     so the interval is widened by |t| * 2^-21 + E with E = 2^-21 * max_axis |oi| (8u |t| + 8u |oi|: twice and
+//     four times the bound, which also swallows the second-order terms and the rounding of the widening
+//     itself).  Because f(t) = t - |t| eps is monotone the widening is applied once, after the max / min over axes;
 //   * t_min is rounded down, the running closest distance is rounded up;
 //   * a box passes unless the widened interval is provably empty (NaNs pass).
 // A zero direction component gives i32 = inf and NaN/inf slab values; fminf/fmaxf ignore NaN so
@@ -36,9 +40,15 @@ RT_HD float cull_round_up(double x) {  // an f32 >= x (inf stays inf)
 RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
   Ray32 q;
   float ox = (float)r.origin.x, oy = (float)r.origin.y, oz = (float)r.origin.z;
+#if defined(__HIP_DEVICE_COMPILE__)
+  q.ix = __builtin_amdgcn_rcpf((float)r.direction.x);
+  q.iy = __builtin_amdgcn_rcpf((float)r.direction.y);
+  q.iz = __builtin_amdgcn_rcpf((float)r.direction.z);
+#else
   q.ix = (float)(1.0 / r.direction.x);
   q.iy = (float)(1.0 / r.direction.y);
   q.iz = (float)(1.0 / r.direction.z);
+#endif
   q.oix = ox * q.ix; q.oiy = oy * q.iy; q.oiz = oz * q.iz;
   float ax = __builtin_fabsf(q.ix) < 1e30f ? __builtin_fabsf(q.oix) : 0.0f;
   float ay = __builtin_fabsf(q.iy) < 1e30f ? __builtin_fabsf(q.oiy) : 0.0f;
@@ -58,8 +68,8 @@ RT_HD bool cull32_may_hit(const float* lo, const float* hi, const Ray32& q, floa
                              __builtin_fmaxf(__builtin_fminf(az, bz), q.t_min));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
                              __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
-  tn = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-22f, tn) - q.err;
-  tf = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-22f, tf) + q.err;
+  tn = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-21f, tn) - q.err;
+  tf = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-21f, tf) + q.err;
   return !(tn > tf);
 }
 
@@ -85,10 +95,10 @@ RT_HD void cull32_may_hit2(const float* lo0, const float* hi0, const float* lo1,
                               __builtin_fmaxf(__builtin_fminf(az1, bz1), q.t_min));
   float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1.x, b1.x), __builtin_fmaxf(a1.y, b1.y)),
                               __builtin_fminf(__builtin_fmaxf(az1, bz1), t_max32));
-  tn0 = __builtin_fmaf(-__builtin_fabsf(tn0), 0x1.0p-22f, tn0) - q.err;
-  tf0 = __builtin_fmaf(__builtin_fabsf(tf0), 0x1.0p-22f, tf0) + q.err;
-  tn1 = __builtin_fmaf(-__builtin_fabsf(tn1), 0x1.0p-22f, tn1) - q.err;
-  tf1 = __builtin_fmaf(__builtin_fabsf(tf1), 0x1.0p-22f, tf1) + q.err;
+  tn0 = __builtin_fmaf(-__builtin_fabsf(tn0), 0x1.0p-21f, tn0) - q.err;
+  tf0 = __builtin_fmaf(__builtin_fabsf(tf0), 0x1.0p-21f, tf0) + q.err;
+  tn1 = __builtin_fmaf(-__builtin_fabsf(tn1), 0x1.0p-21f, tn1) - q.err;
+  tf1 = __builtin_fmaf(__builtin_fabsf(tf1), 0x1.0p-21f, tf1) + q.err;
   *hit0 = !(tn0 > tf0);
   *hit1 = !(tn1 > tf1);
 #else
