@@ -54,7 +54,9 @@ struct DeviceScene {
   unsigned long long* diag = nullptr;
   int vote_blocks_per_cu[2] = {1, 1};
   bool vote_ring[2] = {false, false}; // k_trace_vote keeps a ring of ready primary rays in LDS (when it costs no occupancy)
-  bool single_bvh = false;            // world == one BVH entry -> k_trace_stream applies
+  bool single_bvh = false;            // world == one BVH entry -> k_trace_lds / k_trace_stream / k_trace_wq apply
+  bool vote_ok = false;               // world == one BVH entry + plain primitive entries -> k_trace_vote applies
+  int32_t vote_bvh_pos = 0;           // position of the BVH entry in the top-level list
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
@@ -104,6 +106,10 @@ static void free_device_scene(DeviceScene* ds) {
     if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
   delete ds;
 }
+
+// Load through the constant address space: the address is wave-uniform, the compiler may use a scalar load.
+template <class T>
+__device__ __forceinline__ T dev_load_uniform(const T* p) { return *(const __attribute__((address_space(4))) T*)(p); }
 
 // 64-bit lane mask of a predicate, straight from the compare (HIP's __ballot(int) first materialises 0/1 in a VGPR).
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
                                                             uint32_t npix, double* __restrict__ samples,
                                                             unsigned int* work_counter,
                                                             unsigned long long* diag, uint32_t leaf_weight,
-                                                            uint32_t walk_threshold, uint32_t stack_levels) {
+                                                            uint32_t walk_threshold, uint32_t stack_levels, uint32_t bvh_pos) {
   unsigned long long dg[12];
   if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
 #define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
                                    (threadIdx.x >> 6) * RING_BYTES_PER_WAVE);
   uint32_t* const ring_g = (uint32_t*)(ring_f + RING_F64 * 64);
   uint32_t ring_n = 0;                    // wave-uniform: entries in the ring (a stack)
-  const rt::FlatEntry& bvh = sv.entries[sv.top_level[0]];
+  const rt::FlatEntry& bvh = sv.entries[sv.top_level[bvh_pos]];
   const int32_t root = bvh.a;
   const uint32_t first_ref = (uint32_t)bvh.b;
   uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
@@ -656,6 +662,21 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
     DIAG_ADD(5, wave_ballot(finished));
     if (finished) {
       midwalk = false;
+      if (F & rt::F_PRIM_ENTRY) {
+        // Plain primitives beside the BVH in the top-level list (the dragon room's seven rectangles): tested here,
+        // after the walk, in list order.  HittableList::hit (hit.rs:660-690) lets the LATER entry win an exact
+        // tie, wherever the BVH sits in the list; everything else about a closest hit is order independent.
+        int32_t win_entry = best.hit ? (int32_t)bvh_pos : -1;
+        for (int32_t k = 0; k < sv.n_top_level; ++k) {
+          if (k == (int32_t)bvh_pos) continue;
+          const rt::FlatEntry* e = &sv.entries[dev_load_uniform(&sv.top_level[k])];
+          const rt::PrimRef ref = (rt::PrimRef)dev_load_uniform(&e->a);
+          double t;
+          if (rt::prim_t<F, false>(sv, ref, ps.ray, 0.001, best.t, &t, nullptr)) {
+            if (t < best.t || win_entry < k) { best.t = t; best.ref = ref; best.hit = true; win_entry = k; }
+          }
+        }
+      }
       rt::HitRecord rec;
       if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
       if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
@@ -907,7 +928,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         HIP_TRY(hipMemcpyAsync(&err, ds->error_word, sizeof(err), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
-      } else if (ds->single_bvh && preset < 2 && !ds->force_persistent && !ds->force_stream) {
+      } else if (ds->vote_ok && preset < 2 && !ds->force_persistent && !(ds->force_stream && ds->single_bvh)) {
         kernel_used = RTX_KERNEL_VOTE;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -919,7 +940,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
 #define LAUNCH_VOTE(FEAT, DIAGF, RINGF, DIAGP)                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
-                     ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels)
+                     ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
@@ -1070,6 +1091,15 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       if (nb > 0) ds->vote_blocks_per_cu[1] = nb;
     }
     ds->single_bvh = fs.top_level.size() == 1 && fs.entries[fs.top_level[0]].kind == rt::ENTRY_BVH;
+    {
+      int n_bvh = 0, n_other = 0;
+      for (size_t k = 0; k < fs.top_level.size(); ++k) {
+        const int32_t kind = fs.entries[fs.top_level[k]].kind;
+        if (kind == rt::ENTRY_BVH) { ++n_bvh; ds->vote_bvh_pos = (int32_t)k; }
+        else if (kind != rt::ENTRY_PRIM) ++n_other;
+      }
+      ds->vote_ok = n_bvh == 1 && n_other == 0;
+    }
     if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes32.size() <= LDSK_MAX_NODES) {
       uint32_t max_count = 0, max_end = 0;
       for (const rt::FlatNode& nd : fs.nodes)
