@@ -102,6 +102,27 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+def test_list_ties_between_bvh_and_plain_entries(rtsr, orc):
+    """HittableList::hit (hit.rs:660-690): on an exact tie the LATER list entry wins, wherever the BVH sits.
+
+    World = [rect A, BVH{rect B coplanar with A, sphere}, rect C, rect D coplanar with C]: this shape takes the
+    voting kernel's "one BVH + plain primitives" path, which tests the plain entries after the walk.  A/B tie must go
+    to the BVH (later than A), C/D tie to D, and the GPU must agree with the literal oracle O1 on every pixel."""
+    from test_oracle_pairs import tie_world
+    b, world, cam, cfg, h = tie_world(rtsr)
+    flat = b.flatten(world)
+    scene = flat.upload()
+    st = scene.render_device(cam, cfg, want_stats=True)
+    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_vote"
+    screen = scene.render(cam, cfg)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8)
+    assert np.array_equal(screen.accum, a1)
+    assert np.array_equal(screen.rgb8, r1)
+    # the floor must come out green (the BVH's rect), never red, and the ceiling patch must emit
+    floor_px = screen.accum[24, 48]  # row 0 is the bottom row; (24, 48) looks at the floor in front of the sphere
+    assert floor_px[1] > 4.0 * floor_px[0]
+
+
 def test_device_arithmetic_matches_host(rtsr, orc):
     rng = np.random.default_rng(5)
     n = 200000

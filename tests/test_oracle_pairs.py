@@ -42,6 +42,32 @@ def test_flat_path_equals_literal_path(rtsr, orc, name, sid, width, aspect, spp,
     assert np.array_equal(r1, r2)
 
 
+def tie_world(rtsr):
+    """[rect A, BVH{rect B coplanar with A, sphere}, rect C, rect D coplanar with C]: exact ties between list
+    entries of different kinds.  HittableList::hit (hit.rs:660-690) lets the later entry win: B over A, D over C."""
+    b = rtsr.Builder(1)
+    red, green = b.lambertian((0.8, 0.1, 0.1)), b.lambertian((0.1, 0.8, 0.1))
+    blue, light = b.lambertian((0.1, 0.1, 0.8)), b.diffuse_light((3.0, 3.0, 3.0))
+    inner = b.hittable_list([b.xz_rect(-2, 2, -2, 2, 0.0, green), b.sphere((0.0, 0.6, 0.0), 0.5, b.metal((0.8, 0.8, 0.8), 0.1))])
+    world = b.hittable_list([b.xz_rect(-2, 2, -2, 2, 0.0, red), b.bvh_from_list(inner, 0.0, 1.0),
+                             b.xz_rect(-3, 3, -3, 3, 4.0, blue), b.xz_rect(-3, 3, -3, -1.5, 4.0, light)])
+    cam = rtsr.Camera.new((0.0, 2.0, 6.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 50.0, 1.0, 0.0, 6.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.0, 96, 16, 20, 4, seed=5, background=(0.2, 0.2, 0.2))
+    return b, world, cam, cfg, rtsr.image_height(cfg)
+
+
+def test_list_ties_later_entry_wins(rtsr, orc):
+    b, world, cam, cfg, h = tie_world(rtsr)
+    flat = b.flatten(world)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8)
+    a2, r2 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+    assert np.array_equal(a1, a2) and np.array_equal(r1, r2)
+    floor_px = a1[24, 48]  # row 0 is the bottom row; (24, 48) looks at the floor in front of the sphere
+    assert floor_px[1] > 4.0 * floor_px[0], "the BVH's green rectangle (later entry) must win the tie with the red one"
+    ceiling_px = a1[92, 48] / 16.0  # the emitting patch (later) over the blue ceiling
+    assert ceiling_px.min() > 1.0
+
+
 def test_bvh_topology_does_not_matter(rtsr, orc):
     """Different reference-BVH axis streams (O1) and different SAH leaf sizes (O2): same image."""
     b, world, cam, cfg, h = _scene(rtsr, 100, 64, 1.5, 4, {})
