@@ -1085,7 +1085,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       // preset 1
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_MESH, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_MESH, false, true>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
-      ds->vote_ring[1] = nb1 > 0 && nb1 >= nb0 && lds_ring <= 64 * 1024;
+      ds->vote_ring[1] = false;  // measured on the mesh room: no gain, and the ring's live state spills 50 dwords there
       if (rg && nb1 > 0 && lds_ring <= 64 * 1024) ds->vote_ring[1] = atoi(rg) != 0;
       nb = ds->vote_ring[1] ? nb1 : nb0;
       if (nb > 0) ds->vote_blocks_per_cu[1] = nb;
