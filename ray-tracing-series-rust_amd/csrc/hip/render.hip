@@ -1121,7 +1121,9 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         else if (ldsk_layout(levels, false, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
       }
       if (ds->lds_ok) {
-        const int bytes = (int)ldsk_layout(levels, ds->lds_ring, ds->lds_dims).total;
+        // the limit is a property of the function, not of this scene: raise it to the device maximum once, so that
+        // scenes uploaded earlier (with other LDS sizes) keep launching
+        const int bytes = lds_max;
         hipError_t ae = ds->lds_ring
             ? hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
             : hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1157,8 +1159,9 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       ds->wq_ok = ds->wq_paths > 0 && max_count <= 4 && max_end <= WQ_MAX_SLOTS;
       if (ds->wq_ok && ds->force_wq) {
         const WqLayout L = wq_layout(ds->wq_paths, ds->wq_levels);
-        if (hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess) {
+        (void)L;
+        if (hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_trace_wq<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) {
           (void)hipGetLastError();
           ds->wq_ok = false;
         }

@@ -102,6 +102,21 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+def test_scenes_with_different_lds_footprints_coexist(rtsr, orc):
+    """k_trace_lds sizes its dynamic LDS per scene; scenes uploaded earlier must keep rendering (and keep their
+    results) after a scene with a different footprint has been uploaded and rendered."""
+    setups = [_setup(rtsr, 100, 96, 1.5, 6, {}), _setup(rtsr, 7, 96, 16.0 / 9.0, 6, {}), _setup(rtsr, 13, 96, 16.0 / 9.0, 6, {})]
+    scenes = [s[4].upload() for s in setups]
+    first = [sc.render(s[2], s[3]).accum.copy() for sc, s in zip(scenes, setups)]
+    for sc, s, f in reversed(list(zip(scenes, setups, first))):
+        st = sc.render_device(s[2], s[3], want_stats=True)
+        assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_lds"
+        assert np.array_equal(sc.render(s[2], s[3]).accum, f)
+    b, world, cam, cfg, flat = setups[0]
+    ref, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, rtsr.image_height(cfg), threads=16)
+    assert np.array_equal(first[0], ref)
+
+
 def test_list_ties_between_bvh_and_plain_entries(rtsr, orc):
     """HittableList::hit (hit.rs:660-690): on an exact tie the LATER list entry wins, wherever the BVH sits.
 
