@@ -205,7 +205,7 @@ struct VoteWalk;  // wave-cooperative BVH walker, defined with the voting walk b
 // matter: streams are keyed by (pixel, sample) and every sample owns its output slot.
 #define TRACE_CHUNK 512u
 template <uint32_t F>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_persistent(rt::SceneView sv_in, rt::RenderParams rp,
+__global__ __launch_bounds__(TRACE_BLOCK, (F == P_ALL ? 3 : 1)) void k_trace_persistent(rt::SceneView sv_in, rt::RenderParams rp,
                                                                    ShardMap sm, uint32_t s_begin,
                                                                    uint32_t total, uint32_t npix,
                                                                    double* __restrict__ samples,
