@@ -26,6 +26,9 @@
 namespace rtx {
 
 // ------------------------------------------------------------------ device scene
+struct FlatNode4;
+typedef const FlatNode4 FlatNode4Dev;
+
 struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
   uint32_t n_nodes, n_refs, n_spheres, n_moving;
 };
@@ -55,6 +58,8 @@ struct DeviceScene {
   int vote_blocks_per_cu[2] = {1, 1};
   bool vote_ring[2] = {false, false}; // k_trace_vote keeps a ring of ready primary rays in LDS (when it costs no occupancy)
   bool single_bvh = false;            // world == one BVH entry -> k_trace_lds / k_trace_stream / k_trace_wq apply
+  FlatNode4Dev* nodes4 = nullptr;     // 4-wide culling tree of the BVH entry (big triangle meshes), built at upload
+  int wide_levels = 0, wide_blocks_per_cu = 1;
   bool vote_ok = false;               // world == one BVH entry + plain primitive entries -> k_trace_vote applies
   int32_t vote_bvh_pos = 0;           // position of the BVH entry in the top-level list
   int stream_blocks_per_cu[2] = {1, 1};
@@ -452,6 +457,136 @@ __device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t
   *cur = stack.empty() ? WALK_DONE : stack.pop();
 }
 
+// ------------------------------------------------------------------ 4-wide culling tree (big meshes)
+// On the dragon room the walk is bound by the latency of dependent node fetches (28 MB of culling tree: every step
+// waits for L2 / MALL), not by VALU.  A 4-wide tree halves the length of that chain: built at upload by collapsing the
+// binary SAH tree (the child with the largest area is opened until four slots are used), one 128-byte record = one
+// cache line per step, boxes rounded outward to f32 exactly like FlatNode32.  Wide node i is binary node i opened
+// up, so child codes (node index >= 0, leaf code < 0) are the binary tree's and leaves are untouched.  Culling
+// structure only: every hit is still decided by the f64 primitive tests, so results do not change.
+struct FlatNode4 {  // 128 B, field-major so that one child's six planes are six scalar picks from float4 loads
+  float lo[3][4];
+  float hi[3][4];
+  int32_t child[4];  // WALK_DONE marks an empty slot (its box is empty too)
+  int32_t pad[4];
+};
+static_assert(sizeof(FlatNode4) == 128, "one cache line per wide node");
+
+// Host: collapse fs.nodes below `root` into `out` (indexed like fs.nodes); returns the peak stack use of a walk.
+static int build_wide_nodes(const std::vector<rt::FlatNode>& nodes, int32_t root, std::vector<FlatNode4>* out) {
+  struct Slot { int32_t code; double mn[3], mx[3]; };
+  auto half_area = [](const Slot& s) {
+    double dx = s.mx[0] - s.mn[0], dy = s.mx[1] - s.mn[1], dz = s.mx[2] - s.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  auto slots_of = [&](int32_t n, Slot* dst) {
+    for (int c = 0; c < 2; ++c) {
+      dst[c].code = nodes[n].child[c];
+      for (int a = 0; a < 3; ++a) { dst[c].mn[a] = nodes[n].bmin[c][a]; dst[c].mx[a] = nodes[n].bmax[c][a]; }
+    }
+  };
+  struct Frame { int32_t node; int next; int nslots; int32_t kids[4]; int peak_kids; };
+  std::vector<Frame> stack;
+  std::vector<int> peak(nodes.size(), 0);
+  auto open = [&](int32_t n) {
+    Slot sl[4];
+    int ns = 2;
+    slots_of(n, sl);
+    while (ns < 4) {
+      int best = -1;
+      double best_area = -1.0;
+      for (int k = 0; k < ns; ++k)
+        if (sl[k].code >= 0 && half_area(sl[k]) > best_area) { best_area = half_area(sl[k]); best = k; }
+      if (best < 0) break;
+      Slot two[2];
+      slots_of(sl[best].code, two);
+      sl[best] = two[0];
+      sl[ns++] = two[1];
+    }
+    FlatNode4& w = (*out)[n];
+    Frame f;
+    f.node = n; f.next = 0; f.nslots = ns; f.peak_kids = 0;
+    for (int k = 0; k < 4; ++k) {
+      f.kids[k] = -1;
+      if (k < ns) {
+        for (int a = 0; a < 3; ++a) {
+          float lo = (float)sl[k].mn[a];
+          if ((double)lo > sl[k].mn[a]) lo = std::nextafterf(lo, -INFINITY);
+          float hi = (float)sl[k].mx[a];
+          if ((double)hi < sl[k].mx[a]) hi = std::nextafterf(hi, INFINITY);
+          w.lo[a][k] = lo; w.hi[a][k] = hi;
+        }
+        w.child[k] = sl[k].code;
+        if (sl[k].code >= 0) f.kids[k] = sl[k].code;
+      } else {
+        for (int a = 0; a < 3; ++a) { w.lo[a][k] = INFINITY; w.hi[a][k] = -INFINITY; }
+        w.child[k] = 0x7fffffff;
+      }
+      w.pad[k] = 0;
+    }
+    stack.push_back(f);
+  };
+  open(root);
+  while (!stack.empty()) {
+    Frame& f = stack.back();
+    if (f.next < 4) {
+      int32_t kid = f.kids[f.next++];
+      if (kid >= 0) open(kid);
+      continue;
+    }
+    // all wide children done: a walk pushes up to nslots items here, pops one and descends with nslots - 1 left
+    int pk = f.nslots;
+    for (int k = 0; k < 4; ++k)
+      if (f.kids[k] >= 0) pk = std::max(pk, f.nslots - 1 + peak[f.kids[k]]);
+    peak[f.node] = pk;
+    stack.pop_back();
+  }
+  return peak[root];
+}
+
+// One wide step: test the four child boxes, push the hit ones so that the nearest ends on top, pop it.
+__device__ __forceinline__ bool slab_interval(float lx, float ly, float lz, float hx, float hy, float hz, const rt::Ray32& q,
+                                              float t_max32, float* t_near) {
+  float ax = __builtin_fmaf(lx, q.ix, -q.oix), bx = __builtin_fmaf(hx, q.ix, -q.oix);
+  float ay = __builtin_fmaf(ly, q.iy, -q.oiy), by = __builtin_fmaf(hy, q.iy, -q.oiy);
+  float az = __builtin_fmaf(lz, q.iz, -q.oiz), bz = __builtin_fmaf(hz, q.iz, -q.oiz);
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                             __builtin_fmaxf(__builtin_fminf(az, bz), q.t_min));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                             __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
+  *t_near = tn;
+  float tnw = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-21f, tn) - q.err;  // same widening as cull32_may_hit
+  float tfw = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-21f, tf) + q.err;
+  return !(tnw > tfw);
+}
+__device__ __forceinline__ void walk_node_step4(const FlatNode4* __restrict__ nodes4, const rt::Ray32& q, float t_max32,
+                                                int32_t* cur, LdsStack& stack) {
+  const float4* p = (const float4*)&nodes4[*cur];
+  const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
+  const int4 ch = *(const int4*)&nodes4[*cur].child[0];
+  float k0, k1, k2, k3;
+  const bool h0 = slab_interval(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, q, t_max32, &k0) && ch.x != WALK_DONE;
+  const bool h1 = slab_interval(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, q, t_max32, &k1) && ch.y != WALK_DONE;
+  const bool h2 = slab_interval(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, q, t_max32, &k2) && ch.z != WALK_DONE;
+  const bool h3 = slab_interval(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, q, t_max32, &k3) && ch.w != WALK_DONE;
+  const float inf = __builtin_huge_valf();
+  k0 = h0 ? k0 : inf; k1 = h1 ? k1 : inf; k2 = h2 ? k2 : inf; k3 = h3 ? k3 : inf;
+  // rank = number of children that come before this one (ties: lower slot first); hits rank 0 .. nh-1
+  const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
+  const int r0 = b10 + b20 + b30;
+  const int r1 = (1 - b10) + b21 + b31;
+  const int r2 = (1 - b20) + (1 - b21) + b32;
+  const int r3 = (1 - b30) + (1 - b31) + (1 - b32);
+  const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  const int top = stack.n + nh - 1;  // the nearest hit goes here
+  if (h0) stack.base[(top - r0) * TRACE_BLOCK] = ch.x;
+  if (h1) stack.base[(top - r1) * TRACE_BLOCK] = ch.y;
+  if (h2) stack.base[(top - r2) * TRACE_BLOCK] = ch.z;
+  if (h3) stack.base[(top - r3) * TRACE_BLOCK] = ch.w;
+  stack.n += nh;
+  *cur = stack.empty() ? WALK_DONE : stack.pop();
+}
+
 // The voting walk as a world_hit walker policy (core/geometry.hpp): every lane that reaches a BVH
 // entry walks it together with the rest of its wave.  Top-level entry kinds are the same for all
 // lanes, so the enclosing control flow is wave-uniform up to lanes that already missed.
@@ -495,13 +630,14 @@ struct VoteWalk {
 // once, to top the ring up.  Which lane traces a sample is invisible in the result.
 #define RING_F64 9  // origin(3) direction(3) time rng.s0 rng.s1
 #define RING_BYTES_PER_WAVE (64u * (RING_F64 * 8u + 4u))
-template <uint32_t F, bool DIAG, bool RING>
+template <uint32_t F, bool DIAG, bool RING, bool WIDE>
 __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
                                                             ShardMap sm, uint32_t s_begin, uint32_t total,
                                                             uint32_t npix, double* __restrict__ samples,
                                                             unsigned int* work_counter,
                                                             unsigned long long* diag, uint32_t leaf_weight,
-                                                            uint32_t walk_threshold, uint32_t stack_levels, uint32_t bvh_pos) {
+                                                            uint32_t walk_threshold, uint32_t stack_levels, uint32_t bvh_pos,
+                                                            const FlatNode4* __restrict__ nodes4) {
   unsigned long long dg[12];
   if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
 #define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
@@ -647,7 +783,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
       if ((uint32_t)__popcll(m_node | m_leaf) < threshold) break;
       if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
         DIAG_ADD(2, m_node);
-        if (is_node) walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
+        if (is_node) {
+          if (WIDE) walk_node_step4(nodes4, q, t_max32, &cur, stack);
+          else walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
+        }
       } else {
         DIAG_ADD(3, m_leaf);
         if (is_leaf) {
@@ -938,9 +1077,10 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         const size_t vote_lds = lds_bytes + (ring ? (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE : 0);
         grid = (uint32_t)(want < resident ? want : resident);
 #define LAUNCH_VOTE(FEAT, DIAGF, RINGF, DIAGP)                                                        \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF, false>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
-                     ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos)
+                     ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos, \
+                     (const FlatNode4*)nullptr)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
@@ -954,6 +1094,15 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
                     h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
         }
         else if (preset == 0) { if (ring) { LAUNCH_VOTE(P_SPHERES, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_SPHERES, false, false, (unsigned long long*)nullptr); } }
+        else if (ds->nodes4) {
+          const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
+          uint64_t res4 = (uint64_t)ds->n_cu * (uint64_t)ds->wide_blocks_per_cu;
+          grid = (uint32_t)(want < res4 ? want : res4);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
+                             stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
+                             (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
+                             (uint32_t)ds->vote_bvh_pos, ds->nodes4);
+        }
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
       } else if (ds->single_bvh && preset < 2 && ds->force_stream) {
@@ -1076,15 +1225,15 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       int nb0 = 0, nb1 = 0;
       const char* rg = getenv("RTX_RING");
       // preset 0
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_SPHERES, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_SPHERES, false, true>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_SPHERES, false, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_SPHERES, false, true, false>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
       ds->vote_ring[0] = nb1 > 0 && nb1 >= nb0 && lds_ring <= 64 * 1024;
       if (rg && nb1 > 0 && lds_ring <= 64 * 1024) ds->vote_ring[0] = atoi(rg) != 0;
       nb = ds->vote_ring[0] ? nb1 : nb0;
       if (nb > 0) ds->vote_blocks_per_cu[0] = nb;
       // preset 1
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_MESH, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_MESH, false, true>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_trace_vote<P_MESH, false, false, false>, TRACE_BLOCK, lds) != hipSuccess) nb0 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_trace_vote<P_MESH, false, true, false>, TRACE_BLOCK, lds_ring) != hipSuccess) nb1 = 0;
       ds->vote_ring[1] = false;  // measured on the mesh room: no gain, and the ring's live state spills 50 dwords there
       if (rg && nb1 > 0 && lds_ring <= 64 * 1024) ds->vote_ring[1] = atoi(rg) != 0;
       nb = ds->vote_ring[1] ? nb1 : nb0;
@@ -1099,6 +1248,29 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         else if (kind != rt::ENTRY_PRIM) ++n_other;
       }
       ds->vote_ok = n_bvh == 1 && n_other == 0;
+    }
+    // big triangle BVHs: 4-wide culling tree (see FlatNode4); RTX_WIDE=0/1 overrides the size test
+    {
+      const bool mesh_preset = (fs.features & ~P_SPHERES) != 0 && (fs.features & ~P_MESH) == 0;
+      const char* wd = getenv("RTX_WIDE");
+      bool want_wide = ds->vote_ok && mesh_preset && fs.nodes.size() >= 4096;
+      if (wd) want_wide = ds->vote_ok && mesh_preset && atoi(wd) != 0 && !fs.nodes.empty();
+      if (want_wide) {
+        std::vector<FlatNode4> wide(fs.nodes.size());
+        memset(wide.data(), 0, wide.size() * sizeof(FlatNode4));
+        const int peak = build_wide_nodes(fs.nodes, fs.entries[fs.top_level[ds->vote_bvh_pos]].a, &wide);
+        ds->wide_levels = peak + 1;
+        const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
+        int nbw = 0;
+        if (wide_lds <= 64 * 1024 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbw, k_trace_vote<P_MESH, false, false, true>, TRACE_BLOCK, wide_lds) == hipSuccess && nbw > 0) {
+          const FlatNode4* dptr = nullptr;
+          if ((st = upload_array(ds, wide, &dptr)) != RTX_OK) { free_device_scene(ds); return st; }
+          ds->nodes4 = dptr;
+          ds->wide_blocks_per_cu = nbw;
+        }
+        if (wd) fprintf(stderr, "[rtx] RTX_WIDE: 4-wide tree %s (%d stack levels, %d blocks per CU)\n", ds->nodes4 ? "on" : "off", ds->wide_levels, nbw);
+      }
     }
     if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes32.size() <= LDSK_MAX_NODES) {
       uint32_t max_count = 0, max_end = 0;

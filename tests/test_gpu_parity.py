@@ -102,6 +102,21 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_mesh_room_binary_and_wide_tree(rtsr, orc, monkeypatch, wide):
+    """The dragon room through k_trace_vote with the binary and with the 4-wide culling tree (RTX_WIDE)."""
+    monkeypatch.setenv("RTX_WIDE", wide)
+    b, world, cam, cfg, flat = _setup(rtsr, 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, seed=9)
+    h = rtsr.image_height(cfg)
+    scene = flat.upload()
+    st = scene.render_device(cam, cfg, want_stats=True)
+    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_vote"
+    screen = scene.render(cam, cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    assert np.array_equal(screen.accum, ref_accum)
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+
+
 def test_scenes_with_different_lds_footprints_coexist(rtsr, orc):
     """k_trace_lds sizes its dynamic LDS per scene; scenes uploaded earlier must keep rendering (and keep their
     results) after a scene with a different footprint has been uploaded and rendered."""
