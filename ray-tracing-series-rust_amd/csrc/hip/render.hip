@@ -62,6 +62,7 @@ struct DeviceScene {
   int wide_levels = 0, wide_blocks_per_cu = 1;
   bool vote_ok = false;               // world == one BVH entry + plain primitive entries -> k_trace_vote applies
   int32_t vote_bvh_pos = 0;           // position of the BVH entry in the top-level list
+  int32_t vote_tri_base = -1;         // >= 0: that BVH is a pure triangle mesh whose slot s is triangle vote_tri_base + s
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
@@ -448,12 +449,19 @@ __device__ __forceinline__ void walk_node_step32(const rt::FlatNode32& n, const 
     *cur = stack.empty() ? WALK_DONE : stack.pop();
   }
 }
+// tri_base >= 0: the BVH holds triangles only and slot s is triangle tri_base + s (the flattener stores a mesh's
+// triangles in leaf order), so the primitive reference need not be fetched.
 template <uint32_t F>
 __device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t first_ref, const rt::Ray& r,
-                                               double t_min, rt::Closest* best, int32_t* cur, LdsStack& stack) {
+                                               double t_min, rt::Closest* best, int32_t* cur, LdsStack& stack,
+                                               int32_t tri_base = -1) {
   uint32_t f = rt::leaf_first(*cur), k = rt::leaf_count(*cur);
-  for (uint32_t i = 0; i < k; ++i)
-    rt::offer_prim<F, false>(sv, sv.refs[first_ref + f + i], f + i, r, t_min, best, nullptr);
+  for (uint32_t i = 0; i < k; ++i) {
+    const rt::PrimRef ref = ((F & rt::F_TRIANGLE) && tri_base >= 0)
+                                ? rt::make_primref(rt::PRIM_TRIANGLE, (uint32_t)tri_base + f + i)
+                                : sv.refs[first_ref + f + i];
+    rt::offer_prim<F, false>(sv, ref, f + i, r, t_min, best, nullptr);
+  }
   *cur = stack.empty() ? WALK_DONE : stack.pop();
 }
 
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
                                                             unsigned int* work_counter,
                                                             unsigned long long* diag, uint32_t leaf_weight,
                                                             uint32_t walk_threshold, uint32_t stack_levels, uint32_t bvh_pos,
-                                                            const FlatNode4* __restrict__ nodes4) {
+                                                            const FlatNode4* __restrict__ nodes4, int32_t tri_base) {
   unsigned long long dg[12];
   if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
 #define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv,
       } else {
         DIAG_ADD(3, m_leaf);
         if (is_leaf) {
-          walk_leaf_step<F>(sv, first_ref, ps.ray, 0.001, &best, &cur, stack);
+          walk_leaf_step<F>(sv, first_ref, ps.ray, 0.001, &best, &cur, stack, tri_base);
           t_max32 = rt::cull_round_up(best.t);
         }
       }
@@ -1080,7 +1088,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF, false>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
                      ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos, \
-                     (const FlatNode4*)nullptr)
+                     (const FlatNode4*)nullptr, ds->vote_tri_base)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
@@ -1101,7 +1109,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
                              stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
                              (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
-                             (uint32_t)ds->vote_bvh_pos, ds->nodes4);
+                             (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base);
         }
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
@@ -1248,6 +1256,15 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         else if (kind != rt::ENTRY_PRIM) ++n_other;
       }
       ds->vote_ok = n_bvh == 1 && n_other == 0;
+      if (ds->vote_ok) {
+        const rt::FlatEntry& be = fs.entries[fs.top_level[ds->vote_bvh_pos]];
+        bool pure = be.c > 0 && rt::primref_type(fs.refs[be.b]) == rt::PRIM_TRIANGLE;
+        const uint32_t t0 = pure ? rt::primref_index(fs.refs[be.b]) : 0u;
+        for (int32_t k = 0; pure && k < be.c; ++k)
+          pure = fs.refs[be.b + k] == rt::make_primref(rt::PRIM_TRIANGLE, t0 + (uint32_t)k);
+        const char* tb = getenv("RTX_TRI_DIRECT");
+        if (pure && !(tb && atoi(tb) == 0)) ds->vote_tri_base = (int32_t)t0;
+      }
     }
     // big triangle BVHs: 4-wide culling tree (see FlatNode4); RTX_WIDE=0/1 overrides the size test
     {

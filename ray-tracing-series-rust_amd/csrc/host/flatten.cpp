@@ -218,7 +218,25 @@ struct Flattener {
       e.a = root;
       e.b = (int32_t)out.refs.size();
       e.c = (int32_t)refs.size();
-      for (size_t i = 0; i < refs.size(); ++i) out.refs.push_back(refs[order[i]]);
+      // Triangles of this BVH are permuted (within the set of array slots they already occupy) so that array order
+      // is leaf order: a leaf's triangles become neighbours in memory, and for a pure mesh the slot of a reference
+      // is its triangle index minus a constant, which lets the mesh kernels skip the reference fetch.
+      {
+        std::vector<uint32_t> in_leaf_order;
+        for (size_t i = 0; i < refs.size(); ++i)
+          if (rt::primref_type(refs[order[i]]) == rt::PRIM_TRIANGLE) in_leaf_order.push_back(rt::primref_index(refs[order[i]]));
+        std::vector<uint32_t> sorted_idx = in_leaf_order;
+        std::sort(sorted_idx.begin(), sorted_idx.end());
+        std::vector<rt::FlatTriangle> moved(in_leaf_order.size());
+        for (size_t k = 0; k < in_leaf_order.size(); ++k) moved[k] = out.triangles[in_leaf_order[k]];
+        for (size_t k = 0; k < in_leaf_order.size(); ++k) out.triangles[sorted_idx[k]] = moved[k];
+        size_t k = 0;
+        for (size_t i = 0; i < refs.size(); ++i) {
+          rt::PrimRef r = refs[order[i]];
+          if (rt::primref_type(r) == rt::PRIM_TRIANGLE) r = rt::make_primref(rt::PRIM_TRIANGLE, sorted_idx[k++]);
+          out.refs.push_back(r);
+        }
+      }
       out.max_stack = std::max(out.max_stack, depth);
       out.n_bvh++;
       return push_entry(e);
