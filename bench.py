@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true")
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
+    ap.add_argument("--sah-bins", type=int, default=0, help="SAH bin count override (0 = library default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -110,7 +111,7 @@ def main():
     cfg = rtsr.Config.new(aspect, width, spp, depth, 10, seed=1, background=bg)
     height = rtsr.image_height(cfg)
     t_flat = time.perf_counter()
-    flat = b.flatten(world, max_leaf=args.max_leaf)
+    flat = b.flatten(world, max_leaf=args.max_leaf, sah_bins=args.sah_bins)
     t_flat = time.perf_counter() - t_flat
     scene = flat.upload()
 

@@ -26,6 +26,7 @@
 namespace rtx {
 
 // ------------------------------------------------------------------ device scene
+#define TRACE_CHUNK_DEFAULT 512u
 struct FlatNode4;
 typedef const FlatNode4 FlatNode4Dev;
 
@@ -60,6 +61,7 @@ struct DeviceScene {
   bool single_bvh = false;            // world == one BVH entry -> k_trace_lds / k_trace_stream / k_trace_wq apply
   FlatNode4Dev* nodes4 = nullptr;     // 4-wide culling tree of the BVH entry (big triangle meshes), built at upload
   int wide_levels = 0, wide_blocks_per_cu = 1;
+  int wide_pers_blocks_per_cu[3] = {1, 1, 1};
   bool vote_ok = false;               // world == one BVH entry + plain primitive entries -> k_trace_vote applies
   int32_t vote_bvh_pos = 0;           // position of the BVH entry in the top-level list
   int32_t vote_tri_base = -1;         // >= 0: that BVH is a pure triangle mesh whose slot s is triangle vote_tri_base + s
@@ -68,6 +70,7 @@ struct DeviceScene {
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
+  uint32_t lds_chunk = TRACE_CHUNK_DEFAULT;  // sample indices a wave reserves per grab (RTX_CHUNK)
   LdsSceneDims lds_dims = {0, 0, 0, 0};
   bool force_wq = false;              // RTX_TRACE_KERNEL=wq: workgroup-queue kernel (trace_wq.inc)
   bool wq_diag = false;               // RTX_TRACE_KERNEL=wq_diag: stage occupancy counters on stderr (never timed)
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_simple(rt::SceneView sv, 
   if (COUNT) flush_counters(cnt, counters);
 }
 
-struct VoteWalk;  // wave-cooperative BVH walker, defined with the voting walk below
+template <bool WIDE> struct VoteWalkT;  // wave-cooperative BVH walker, defined with the voting walk below
 
 // Persistent waves with path regeneration.  The pass's samples form one index space
 // [0, total); waves pull chunks of it from a global counter and hand indices to their lanes
@@ -210,7 +213,9 @@ struct VoteWalk;  // wave-cooperative BVH walker, defined with the voting walk b
 // work, whatever the length of its neighbours' paths.  Which lane runs which sample cannot
 // matter: streams are keyed by (pixel, sample) and every sample owns its output slot.
 #define TRACE_CHUNK 512u
-template <uint32_t F>
+// WIDE: sv_in.nodes carries the 4-wide culling tree (FlatNode4, see below) instead of the f64 binary tree, which
+// this kernel never reads.
+template <uint32_t F, bool WIDE>
 __global__ __launch_bounds__(TRACE_BLOCK, (F == P_ALL ? 3 : 1)) void k_trace_persistent(rt::SceneView sv_in, rt::RenderParams rp,
                                                                    ShardMap sm, uint32_t s_begin,
                                                                    uint32_t total, uint32_t npix,
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (F == P_ALL ? 3 : 1)) void k_trace_per
     }
     if (wave_ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
     if (active) {
-      if (rt::path_step<F, false, LdsStack, VoteWalk>(sv, rp, &ps, stack, nullptr)) {
+      if (rt::path_step<F, false, LdsStack, VoteWalkT<WIDE>>(sv, rp, &ps, stack, nullptr)) {
         double* o = samples + 3 * (size_t)g;
         o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
         active = false;
@@ -598,7 +603,8 @@ __device__ __forceinline__ void walk_node_step4(const FlatNode4* __restrict__ no
 // The voting walk as a world_hit walker policy (core/geometry.hpp): every lane that reaches a BVH
 // entry walks it together with the rest of its wave.  Top-level entry kinds are the same for all
 // lanes, so the enclosing control flow is wave-uniform up to lanes that already missed.
-struct VoteWalk {
+template <bool WIDE>
+struct VoteWalkT {
   template <uint32_t F, bool COUNT, class STACK>
   __device__ __forceinline__ static void run(const rt::SceneView& sv, int32_t root, uint32_t first_ref,
                                              const rt::Ray& r, double t_min, rt::Closest* best, STACK& stack,
@@ -614,7 +620,10 @@ struct VoteWalk {
       unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
       if ((m_node | m_leaf) == 0ull) break;
       if ((uint32_t)__popcll(m_node) * 3u >= (uint32_t)__popcll(m_leaf)) {
-        if (is_node) walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
+        if (is_node) {
+          if (WIDE) walk_node_step4((const FlatNode4*)sv.nodes, q, t_max32, &cur, stack);
+          else walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
+        }
       } else {
         if (is_leaf) {
           walk_leaf_step<F>(sv, first_ref, r, t_min, best, &cur, stack);
@@ -1038,7 +1047,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
 #define LAUNCH_LDS(RINGF)                                                                              \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<P_SPHERES, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, ds->lds_dims)
+                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, (uint32_t)stack_levels, ds->lds_dims)
         if (ds->lds_ring) { LAUNCH_LDS(true); } else { LAUNCH_LDS(false); }
 #undef LAUNCH_LDS
       } else if (ds->force_wq && ds->wq_ok && preset == 0) {
@@ -1132,15 +1141,24 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->blocks_per_cu[preset];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
-#define LAUNCH_PERSISTENT(FEAT)                                                                       \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_persistent<FEAT>), dim3(grid), dim3(TRACE_BLOCK),        \
-                     lds_bytes, stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, \
+#define LAUNCH_PERSISTENT(FEAT, WIDEF, VIEW, LDSB)                                                     \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_persistent<FEAT, WIDEF>), dim3(grid), dim3(TRACE_BLOCK),  \
+                     LDSB, stream, VIEW, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
                      ds->work_counter, ds->view.entries, ds->view.top_level, ds->view.spheres,             \
                      ds->view.moving_spheres, ds->view.rects, ds->view.triangles, ds->view.materials,      \
                      ds->view.textures, ds->view.refs)
-        if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES); }
-        else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH); }
-        else { LAUNCH_PERSISTENT(P_ALL); }
+        if (ds->nodes4 && preset >= 1) {
+          rt::SceneView wv = ds->view;
+          wv.nodes = (const rt::FlatNode*)ds->nodes4;  // the wide tree rides in the slot of the (unused) f64 tree
+          const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
+          resident = (uint64_t)ds->n_cu * (uint64_t)ds->wide_pers_blocks_per_cu[preset];
+          grid = (uint32_t)(want < resident ? want : resident);
+          if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, true, wv, wide_lds); }
+          else { LAUNCH_PERSISTENT(P_ALL, true, wv, wide_lds); }
+        }
+        else if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES, false, ds->view, lds_bytes); }
+        else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, false, ds->view, lds_bytes); }
+        else { LAUNCH_PERSISTENT(P_ALL, false, ds->view, lds_bytes); }
 #undef LAUNCH_PERSISTENT
       }
       HIP_TRY(hipGetLastError());
@@ -1217,9 +1235,9 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       ds->n_cu = prop.multiProcessorCount;
     size_t lds = (size_t)(fs.max_stack + 1) * TRACE_BLOCK * sizeof(int32_t);
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[1] = nb;
     const char* k = getenv("RTX_TRACE_KERNEL");
@@ -1266,27 +1284,42 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         if (pure && !(tb && atoi(tb) == 0)) ds->vote_tri_base = (int32_t)t0;
       }
     }
-    // big triangle BVHs: 4-wide culling tree (see FlatNode4); RTX_WIDE=0/1 overrides the size test
+    // 4-wide culling tree (see FlatNode4) for every BVH of the scene: big triangle meshes under k_trace_vote, and any
+    // world that takes k_trace_persistent (Book-2: two BVHs walked per bounce, each step a dependent L2 fetch).
+    // RTX_WIDE=0/1 overrides the size tests.
     {
-      const bool mesh_preset = (fs.features & ~P_SPHERES) != 0 && (fs.features & ~P_MESH) == 0;
+      const bool spheres_preset = (fs.features & ~P_SPHERES) == 0;
+      const bool mesh_preset = !spheres_preset && (fs.features & ~P_MESH) == 0;
+      const int preset_i = spheres_preset ? 0 : (mesh_preset ? 1 : 2);
       const char* wd = getenv("RTX_WIDE");
-      bool want_wide = ds->vote_ok && mesh_preset && fs.nodes.size() >= 4096;
-      if (wd) want_wide = ds->vote_ok && mesh_preset && atoi(wd) != 0 && !fs.nodes.empty();
+      const bool for_vote = ds->vote_ok && mesh_preset;
+      const bool for_pers = !(ds->vote_ok && preset_i < 2) && preset_i >= 1;
+      bool want_wide = (for_vote && fs.nodes.size() >= 4096) || (for_pers && fs.nodes.size() >= 256);
+      if (wd) want_wide = (for_vote || for_pers) && atoi(wd) != 0 && !fs.nodes.empty();
       if (want_wide) {
         std::vector<FlatNode4> wide(fs.nodes.size());
         memset(wide.data(), 0, wide.size() * sizeof(FlatNode4));
-        const int peak = build_wide_nodes(fs.nodes, fs.entries[fs.top_level[ds->vote_bvh_pos]].a, &wide);
+        int peak = 0;
+        for (const rt::FlatEntry& e : fs.entries)
+          if (e.kind == rt::ENTRY_BVH) peak = std::max(peak, build_wide_nodes(fs.nodes, e.a, &wide));
         ds->wide_levels = peak + 1;
         const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
         int nbw = 0;
-        if (wide_lds <= 64 * 1024 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbw, k_trace_vote<P_MESH, false, false, true>, TRACE_BLOCK, wide_lds) == hipSuccess && nbw > 0) {
+        bool ok = wide_lds <= 64 * 1024;
+        if (ok && for_vote) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbw, k_trace_vote<P_MESH, false, false, true>, TRACE_BLOCK, wide_lds) == hipSuccess && nbw > 0;
+        if (ok && for_vote) ds->wide_blocks_per_cu = nbw;
+        if (ok) {
+          int n1 = 0, n2 = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_trace_persistent<P_MESH, true>, TRACE_BLOCK, wide_lds) == hipSuccess && n1 > 0) ds->wide_pers_blocks_per_cu[1] = n1;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_trace_persistent<P_ALL, true>, TRACE_BLOCK, wide_lds) == hipSuccess && n2 > 0) ds->wide_pers_blocks_per_cu[2] = n2;
+          ok = n1 > 0 && n2 > 0;
+        }
+        if (ok) {
           const FlatNode4* dptr = nullptr;
           if ((st = upload_array(ds, wide, &dptr)) != RTX_OK) { free_device_scene(ds); return st; }
           ds->nodes4 = dptr;
-          ds->wide_blocks_per_cu = nbw;
         }
-        if (wd) fprintf(stderr, "[rtx] RTX_WIDE: 4-wide tree %s (%d stack levels, %d blocks per CU)\n", ds->nodes4 ? "on" : "off", ds->wide_levels, nbw);
+        if (wd) fprintf(stderr, "[rtx] RTX_WIDE: 4-wide tree %s (%d stack levels)\n", ds->nodes4 ? "on" : "off", ds->wide_levels);
       }
     }
     if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes32.size() <= LDSK_MAX_NODES) {
@@ -1302,6 +1335,8 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       if (lds_max > 160 * 1024) lds_max = 160 * 1024;
       ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size()};
       const uint32_t levels = (uint32_t)fs.max_stack + 1u;
+      const char* ck = getenv("RTX_CHUNK");
+      if (ck && atoi(ck) >= 64 && atoi(ck) <= 65536) ds->lds_chunk = (uint32_t)atoi(ck);
       const char* sl = getenv("RTX_SCENE_LDS");
       const char* rg = getenv("RTX_RING");
       const bool want_ring = !(rg && atoi(rg) == 0);

@@ -102,15 +102,24 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+WIDE_CASES = [  # (name, scene id, width, aspect, spp, options, expected kernel)
+    ("dragon_room", 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, "k_trace_vote"),
+    ("book2_final", 6, 96, 1.0, 6, {}, "k_trace_persistent"),
+    ("cornell_box", 4, 80, 1.0, 6, {}, "k_trace_persistent"),
+    ("nested_lists", 9, 96, 16.0 / 9.0, 4, {}, "k_trace_persistent"),
+]
+
+
 @pytest.mark.parametrize("wide", ["0", "1"])
-def test_mesh_room_binary_and_wide_tree(rtsr, orc, monkeypatch, wide):
-    """The dragon room through k_trace_vote with the binary and with the 4-wide culling tree (RTX_WIDE)."""
+@pytest.mark.parametrize("name,sid,width,aspect,spp,opts,kernel", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_binary_and_wide_culling_tree(rtsr, orc, monkeypatch, wide, name, sid, width, aspect, spp, opts, kernel):
+    """Worlds walked through the binary and through the 4-wide culling tree (RTX_WIDE forces either)."""
     monkeypatch.setenv("RTX_WIDE", wide)
-    b, world, cam, cfg, flat = _setup(rtsr, 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, seed=9)
+    b, world, cam, cfg, flat = _setup(rtsr, sid, width, aspect, spp, opts, seed=9)
     h = rtsr.image_height(cfg)
     scene = flat.upload()
     st = scene.render_device(cam, cfg, want_stats=True)
-    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_vote"
+    assert rtsr.trace_kernel_name(st.trace_kernel) == kernel
     screen = scene.render(cam, cfg)
     ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
     assert np.array_equal(screen.accum, ref_accum)
