@@ -15,7 +15,9 @@
 //         |t - T| <= 4u |t| + 2u |oi|
 //     so the interval is widened by |t| * 2^-21 + E with E = 2^-21 * max_axis |oi| (8u |t| + 8u |oi|: twice and
 //     four times the bound, which also swallows the second-order terms and the rounding of the widening
-//     itself).  Because f(t) = t - |t| eps is monotone the widening is applied once, after the max / min over axes;
+//     itself).  Because f(t) = t - |t| eps is monotone the widening is applied once, after the max / min over axes,
+//     and as ONE comparison: "widened near > widened far"  <=>  tn - tf > (|tn| + |tf|) 2^-21 + 2E
+//     (4 instructions per box instead of 6; the rounding of the difference, <= u (|tn| + |tf|), sits inside the slack);
 //   * t_min is rounded down, the running closest distance is rounded up;
 //   * a box passes unless the widened interval is provably empty (NaNs pass).
 // A zero direction component gives i32 = inf and NaN/inf slab values; fminf/fmaxf ignore NaN so
@@ -29,7 +31,7 @@ namespace rt {
 struct Ray32 {
   float ix, iy, iz;     // fl(1/d)
   float oix, oiy, oiz;  // fl(o32 * i32)
-  float err;            // E = 2^-21 * max |oi| over axes with finite slope
+  float err2;           // 2E, E = 2^-21 * max |oi| over axes with finite slope
   float t_min;          // rounded down
 };
 
@@ -53,7 +55,7 @@ RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
   float ax = __builtin_fabsf(q.ix) < 1e30f ? __builtin_fabsf(q.oix) : 0.0f;
   float ay = __builtin_fabsf(q.iy) < 1e30f ? __builtin_fabsf(q.oiy) : 0.0f;
   float az = __builtin_fabsf(q.iz) < 1e30f ? __builtin_fabsf(q.oiz) : 0.0f;
-  q.err = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az)) * 0x1.0p-21f;
+  q.err2 = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az)) * 0x1.0p-20f;
   // rounded DOWN whatever the sign (a medium's second boundary query may start at a negative t)
   q.t_min = (float)t_min * (t_min >= 0.0 ? 0.99999988f : 1.00000012f);
   return q;
@@ -68,9 +70,7 @@ RT_HD bool cull32_may_hit(const float* lo, const float* hi, const Ray32& q, floa
                              __builtin_fmaxf(__builtin_fminf(az, bz), q.t_min));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
                              __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
-  tn = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-21f, tn) - q.err;
-  tf = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-21f, tf) + q.err;
-  return !(tn > tf);
+  return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));
 }
 
 // Both children of a node at once.  Same arithmetic as two cull32_may_hit calls; on the device the twelve plane
@@ -95,12 +95,8 @@ RT_HD void cull32_may_hit2(const float* lo0, const float* hi0, const float* lo1,
                               __builtin_fmaxf(__builtin_fminf(az1, bz1), q.t_min));
   float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1.x, b1.x), __builtin_fmaxf(a1.y, b1.y)),
                               __builtin_fminf(__builtin_fmaxf(az1, bz1), t_max32));
-  tn0 = __builtin_fmaf(-__builtin_fabsf(tn0), 0x1.0p-21f, tn0) - q.err;
-  tf0 = __builtin_fmaf(__builtin_fabsf(tf0), 0x1.0p-21f, tf0) + q.err;
-  tn1 = __builtin_fmaf(-__builtin_fabsf(tn1), 0x1.0p-21f, tn1) - q.err;
-  tf1 = __builtin_fmaf(__builtin_fabsf(tf1), 0x1.0p-21f, tf1) + q.err;
-  *hit0 = !(tn0 > tf0);
-  *hit1 = !(tn1 > tf1);
+  *hit0 = !(tn0 - tf0 > __builtin_fmaf(__builtin_fabsf(tn0) + __builtin_fabsf(tf0), 0x1.0p-21f, q.err2));
+  *hit1 = !(tn1 - tf1 > __builtin_fmaf(__builtin_fabsf(tn1) + __builtin_fabsf(tf1), 0x1.0p-21f, q.err2));
 #else
   *hit0 = cull32_may_hit(lo0, hi0, q, t_max32);
   *hit1 = cull32_may_hit(lo1, hi1, q, t_max32);

@@ -568,9 +568,7 @@ __device__ __forceinline__ bool slab_interval(float lx, float ly, float lz, floa
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
                              __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
   *t_near = tn;
-  float tnw = __builtin_fmaf(-__builtin_fabsf(tn), 0x1.0p-21f, tn) - q.err;  // same widening as cull32_may_hit
-  float tfw = __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-21f, tf) + q.err;
-  return !(tnw > tfw);
+  return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));  // as cull32_may_hit
 }
 __device__ __forceinline__ void walk_node_step4(const FlatNode4* __restrict__ nodes4, const rt::Ray32& q, float t_max32,
                                                 int32_t* cur, LdsStack& stack) {
