@@ -187,16 +187,27 @@ def main():
             samples_per_launch = float(my_rows) * width * spp / max(1, launches // max(1, args.steps))
             achieved = bytes_per_sample * samples_per_launch / (mean_trace_ms * 1e-3) / 1e9
             pmc = None
+            valu_issue = None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_path):
                 try:
                     rec = json.load(open(pmc_path))
                     if rec.get("workload") == args.workload and rec.get("spp") == spp and world_size == 1:
                         pmc = rec.get("hbm_bytes_per_launch")
+                        sq = rec.get("sq") or {}
+                        if sq.get("SQ_INSTS_VALU") and sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAVES"):
+                            # what actually bounds this kernel (the scene is on chip): VALU issue.  A SIMD issues one
+                            # wave64 VALU instruction per 4 clocks; SQ cycle counters tick once per 4 clocks.
+                            simds = 4.0 * torch.cuda.get_device_properties(0).multi_processor_count
+                            quad_cycles = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]  # kernel duration, every wave lives through it
+                            valu_issue = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"],
+                                          "frac_of_issue_peak": round(sq["SQ_ACTIVE_INST_VALU"] / (simds * quad_cycles), 3),
+                                          "lane_utilisation": round(rec.get("lane_utilisation", 0.0), 3),
+                                          "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_* pass of this workload)"}
                 except Exception:
                     pmc = None
             roofline = {"bound": "hbm", "kernel": rtsr.trace_kernel_name(kernel_used[-1]) if kernel_used else "?", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc, "valu_issue": valu_issue,
                         "bytes_per_sample": round(bytes_per_sample, 1), "kernel_ms": round(mean_trace_ms, 3),
                         "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),
                         "box_tests_per_ray": round(counts["box_tests"] / float(max(1, counts["rays"])), 2),
