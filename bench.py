@@ -214,7 +214,7 @@ def main():
                         "counted_on": "%d spp of the same pixels and seeds" % count_spp,
                         "per_ray": {k: round(v / float(max(1, counts["rays"])), 3) for k, v in counts.items() if k not in ("rays", "samples") and v}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:  # a reported baseline: rank 0 at N=1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py as orc
             ccfg = rtsr.RtxConfig.from_buffer_copy(cfg)
