@@ -612,12 +612,13 @@ struct VoteWalkT {
     float t_max32 = rt::cull_round_up(best->t);
     stack.reset();
     int32_t cur = root;
+    const uint32_t leaf_weight = sv.pad ? sv.pad : 3u;  // the launcher passes the vote weight in SceneView.pad
     for (;;) {
       bool is_leaf = cur < 0;
       bool is_node = !is_leaf && cur != WALK_DONE;
       unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
       if ((m_node | m_leaf) == 0ull) break;
-      if ((uint32_t)__popcll(m_node) * 3u >= (uint32_t)__popcll(m_leaf)) {
+      if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
         if (is_node) {
           if (WIDE) walk_node_step4((const FlatNode4*)sv.nodes, q, t_max32, &cur, stack);
           else walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
@@ -1145,8 +1146,10 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
                      ds->work_counter, ds->view.entries, ds->view.top_level, ds->view.spheres,             \
                      ds->view.moving_spheres, ds->view.rects, ds->view.triangles, ds->view.materials,      \
                      ds->view.textures, ds->view.refs)
+        rt::SceneView pv = ds->view;
+        pv.pad = ds->leaf_weight;
         if (ds->nodes4 && preset >= 1) {
-          rt::SceneView wv = ds->view;
+          rt::SceneView wv = pv;
           wv.nodes = (const rt::FlatNode*)ds->nodes4;  // the wide tree rides in the slot of the (unused) f64 tree
           const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
           resident = (uint64_t)ds->n_cu * (uint64_t)ds->wide_pers_blocks_per_cu[preset];
@@ -1154,9 +1157,9 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, true, wv, wide_lds); }
           else { LAUNCH_PERSISTENT(P_ALL, true, wv, wide_lds); }
         }
-        else if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES, false, ds->view, lds_bytes); }
-        else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, false, ds->view, lds_bytes); }
-        else { LAUNCH_PERSISTENT(P_ALL, false, ds->view, lds_bytes); }
+        else if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES, false, pv, lds_bytes); }
+        else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, false, pv, lds_bytes); }
+        else { LAUNCH_PERSISTENT(P_ALL, false, pv, lds_bytes); }
 #undef LAUNCH_PERSISTENT
       }
       HIP_TRY(hipGetLastError());
