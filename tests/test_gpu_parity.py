@@ -102,6 +102,25 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+@pytest.mark.parametrize("scene_seed", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("sid", [100, 13])
+def test_other_scene_seeds(rtsr, orc, scene_seed, sid):
+    """Different random sphere layouts give different tree depths and LDS footprints (with / without room for the
+    primary-ray ring): the LDS kernel must agree with the oracle on all of them."""
+    b = rtsr.Builder(scene_seed)
+    world, cam, bg = b.get_world_cam(sid)
+    cfg = rtsr.Config.new(1.5, 120, 6, 50, 10, seed=scene_seed, background=bg)
+    flat = b.flatten(world)
+    h = rtsr.image_height(cfg)
+    scene = flat.upload()
+    st = scene.render_device(cam, cfg, want_stats=True)
+    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_lds"
+    screen = scene.render(cam, cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    assert np.array_equal(screen.accum, ref_accum)
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+
+
 WIDE_CASES = [  # (name, scene id, width, aspect, spp, options, expected kernel)
     ("dragon_room", 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, "k_trace_vote"),
     ("book2_final", 6, 96, 1.0, 6, {}, "k_trace_persistent"),
