@@ -164,744 +164,11 @@ __device__ __forceinline__ void flush_counters(const rt::TraceCounters& c, rt::T
 }
 
 // ------------------------------------------------------------------ kernels
-// Feature presets the trace kernels are compiled for (see core/flat_types.hpp Feature).
-constexpr uint32_t P_SPHERES = rt::F_SPHERE | rt::F_MOVING_SPHERE | rt::F_BVH | rt::F_LAMBERTIAN |
-                               rt::F_METAL | rt::F_DIELECTRIC | rt::F_CHECKER;
-constexpr uint32_t P_MESH = rt::F_SPHERE | rt::F_RECT | rt::F_TRIANGLE | rt::F_PRIM_ENTRY | rt::F_GROUP |
-                            rt::F_BVH | rt::F_LAMBERTIAN | rt::F_METAL | rt::F_DIELECTRIC | rt::F_LIGHT;
-constexpr uint32_t P_ALL = rt::F_ALL;
-
-// Straightforward form: grid-stride over the pass's (sample, pixel) index space, one whole
-// path per loop iteration.  g = s_local * npix + lp, so a wave's lanes are 64 consecutive
-// pixels of the same sample: coherent primary rays, coalesced sample-buffer stores.
-// Kept as the A/B partner of k_trace_persistent (RTX_TRACE_KERNEL=simple) and as the
-// instrumented (COUNT) build.
-template <uint32_t F, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_simple(rt::SceneView sv, rt::RenderParams rp,
-                                                               ShardMap sm, uint32_t s_begin,
-                                                               uint32_t total, uint32_t npix,
-                                                               double* __restrict__ samples,
-                                                               rt::TraceCounters* counters) {
-  extern __shared__ int32_t lds_stack[];
-  LdsStack stack;
-  stack.base = lds_stack + threadIdx.x;
-  stack.n = 0;
-  rt::TraceCounters cnt;
-  if (COUNT) memset(&cnt, 0, sizeof(cnt));
-  for (uint64_t g64 = (uint64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x; g64 < total;
-       g64 += (uint64_t)gridDim.x * TRACE_BLOCK) {
-    uint32_t g = (uint32_t)g64;
-    uint32_t s_local = g / npix;
-    uint32_t lp = g - s_local * npix;
-    uint32_t i, j;
-    shard_pixel(sm, lp, &i, &j);
-    rt::Color c = rt::trace_sample<F, COUNT>(sv, rp, i, j, s_begin + s_local, stack, &cnt);
-    double* o = samples + 3 * (size_t)g;
-    o[0] = c.x; o[1] = c.y; o[2] = c.z;
-  }
-  if (COUNT) flush_counters(cnt, counters);
-}
-
-template <bool WIDE> struct VoteWalkT;  // wave-cooperative BVH walker, defined with the voting walk below
-
-// Persistent waves with path regeneration.  The pass's samples form one index space
-// [0, total); waves pull chunks of it from a global counter and hand indices to their lanes
-// as lanes finish paths: every loop iteration the lanes without a path are compacted with a
-// 64-bit __ballot and ranked with mbcnt (the wavefront prefix sum), take consecutive indices
-// (= consecutive pixels of one sample: coherent camera rays) and start a new path, then ALL
-// lanes advance their path by one bounce.  A lane therefore never idles while the queue has
-// work, whatever the length of its neighbours' paths.  Which lane runs which sample cannot
-// matter: streams are keyed by (pixel, sample) and every sample owns its output slot.
-#define TRACE_CHUNK 512u
-// WIDE: sv_in.nodes carries the 4-wide culling tree (FlatNode4, see below) instead of the f64 binary tree, which
-// this kernel never reads.
-template <uint32_t F, bool WIDE>
-__global__ __launch_bounds__(TRACE_BLOCK, (F == P_ALL ? 3 : 1)) void k_trace_persistent(rt::SceneView sv_in, rt::RenderParams rp,
-                                                                   ShardMap sm, uint32_t s_begin,
-                                                                   uint32_t total, uint32_t npix,
-                                                                   double* __restrict__ samples,
-                                                                   unsigned int* __restrict__ work_counter,
-                                                                   const rt::FlatEntry* __restrict__ entries_ro,
-                                                                   const int32_t* __restrict__ top_level_ro,
-                                                                   const rt::FlatSphere* __restrict__ spheres_ro,
-                                                                   const rt::FlatMovingSphere* __restrict__ msph_ro,
-                                                                   const rt::FlatRect* __restrict__ rects_ro,
-                                                                   const rt::FlatTriangle* __restrict__ tris_ro,
-                                                                   const rt::FlatMaterial* __restrict__ mats_ro,
-                                                                   const rt::FlatTexture* __restrict__ tex_ro,
-                                                                   const rt::PrimRef* __restrict__ refs_ro) {
-  // The world table is read through `const __restrict__` kernel parameters: that is what lets the
-  // compiler prove the kernel's own stores cannot clobber it and fetch the (wave-uniform) entries with
-  // scalar loads -- one s_load per wave instead of 64 identical vector loads per lane.
-  rt::SceneView sv = sv_in;
-  sv.entries = entries_ro;
-  sv.top_level = top_level_ro;
-  sv.spheres = spheres_ro; sv.moving_spheres = msph_ro; sv.rects = rects_ro; sv.triangles = tris_ro;
-  sv.materials = mats_ro; sv.textures = tex_ro; sv.refs = refs_ro;
-  extern __shared__ int32_t lds_stack[];
-  LdsStack stack;
-  stack.base = lds_stack + threadIdx.x;
-  stack.n = 0;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
-  bool queue_empty = false;               // wave-uniform
-  bool active = false;
-  uint32_t g = 0;
-  rt::PathState ps;
-  for (;;) {
-    unsigned long long need_mask = wave_ballot(!active);
-    if (need_mask != 0ull) {
-      if (chunk_pos >= chunk_end && !queue_empty) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= total) {
-          queue_empty = true;
-        } else {
-          chunk_pos = base;
-          chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
-        }
-      }
-      if (chunk_pos < chunk_end) {
-        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-        uint32_t n_need = (uint32_t)__popcll(need_mask);
-        uint32_t avail = chunk_end - chunk_pos;
-        if (!active && rank < avail) {
-          g = chunk_pos + rank;
-          uint32_t s_local = g / npix;
-          uint32_t lp = g - s_local * npix;
-          uint32_t i, j;
-          shard_pixel(sm, lp, &i, &j);
-          rt::path_begin(rp, i, j, s_begin + s_local, &ps);
-          active = true;
-        }
-        chunk_pos += (n_need < avail) ? n_need : avail;
-      }
-    }
-    if (wave_ballot(active) == 0ull) break;  // queue drained and every lane's path has ended
-    if (active) {
-      if (rt::path_step<F, false, LdsStack, VoteWalkT<WIDE>>(sv, rp, &ps, stack, nullptr)) {
-        double* o = samples + 3 * (size_t)g;
-        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
-        active = false;
-      }
-    }
-  }
-}
-
-// Stage-synchronous persistent kernel for worlds that are ONE BVH (Book-1: world = BvhNode,
-// world.rs:162-166).  k_trace_persistent keeps every lane busy at BOUNCE granularity, but inside a
-// bounce the wave still walks the BVH until its slowest ray is done (measured: 31 % VALU lane
-// utilisation).  Here the walk itself is resumable (core/geometry.hpp bvh_step) and a lane is in
-// one of three stages:
-//     NEED   no path: wants a sample index          (regenerated with __ballot + mbcnt compaction)
-//     WALK   its ray is inside the BVH               (one bvh_step per inner iteration)
-//     SHADE  walk finished: wants finalize + scatter (path_bounce_end) -> WALK again or NEED
-// The wave alternates two phases: (1) ALL lanes that are not walking shade / regenerate together,
-// (2) node steps run while at least `walk_threshold` lanes are still walking (all remaining ones
-// once the queue is empty).  Lanes that finish a walk wait at most until the walking population
-// falls under the threshold, so both phases run with a well-filled wave instead of the whole wave
-// waiting for the longest walk of every bounce.  Which lane does what is invisible in the result.
-enum : int { STAGE_NEED = 0, STAGE_WALK = 1, STAGE_SHADE = 2 };
-template <uint32_t F>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_stream(rt::SceneView sv, rt::RenderParams rp,
-                                                              ShardMap sm, uint32_t s_begin,
-                                                              uint32_t total, uint32_t npix,
-                                                              double* __restrict__ samples,
-                                                              unsigned int* work_counter,
-                                                              uint32_t walk_threshold) {
-  extern __shared__ int32_t lds_stack[];
-  LdsStack stack;
-  stack.base = lds_stack + threadIdx.x;
-  stack.n = 0;
-  const uint32_t lane = threadIdx.x & 63u;
-  const rt::FlatEntry& bvh = sv.entries[sv.top_level[0]];
-  const int32_t root = bvh.a;
-  const uint32_t first_ref = (uint32_t)bvh.b;
-  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
-  bool queue_empty = false;               // wave-uniform
-  int stage = STAGE_NEED;
-  uint32_t g = 0;
-  rt::PathState ps;
-  rt::Closest best;
-  rt::Vec3 inv_d = rt::v3(0, 0, 0);
-  uint32_t dir_neg = 0;
-  int32_t node = -1;  // -1: the lane's ray has not begun its bounce yet (phase 1c), >= 0: mid-walk
-  best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
-  for (;;) {
-    // ---- phase 1a: shade the lanes whose walk has finished
-    if (stage == STAGE_SHADE) {
-      rt::HitRecord rec;
-      if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
-      if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
-        double* o = samples + 3 * (size_t)g;
-        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
-        stage = STAGE_NEED;
-      } else {
-        stage = STAGE_WALK;  // new ray: bounce begins below
-      }
-    }
-    // ---- phase 1b: regenerate (wave-cooperative; executed by the whole wave)
-    {
-      unsigned long long need_mask = wave_ballot(stage == STAGE_NEED);
-      if (need_mask != 0ull) {
-        if (chunk_pos >= chunk_end && !queue_empty) {
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= total) {
-            queue_empty = true;
-          } else {
-            chunk_pos = base;
-            chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
-          }
-        }
-        if (chunk_pos < chunk_end) {
-          uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-          uint32_t n_need = (uint32_t)__popcll(need_mask);
-          uint32_t avail = chunk_end - chunk_pos;
-          if (stage == STAGE_NEED && rank < avail) {
-            g = chunk_pos + rank;
-            uint32_t s_local = g / npix;
-            uint32_t lp = g - s_local * npix;
-            uint32_t i, j;
-            shard_pixel(sm, lp, &i, &j);
-            rt::path_begin(rp, i, j, s_begin + s_local, &ps);
-            stage = STAGE_WALK;  // node == -1 here: phase 1c begins the first bounce
-          }
-          chunk_pos += (n_need < avail) ? n_need : avail;
-        }
-      }
-    }
-    // ---- phase 1c: begin the bounce of every lane that has a new ray (world.rs:64-68)
-    if (stage == STAGE_WALK && node < 0) {
-      if (rt::path_bounce_begin(&ps)) {  // depth exhausted: the path ends with what it gathered
-        double* o = samples + 3 * (size_t)g;
-        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
-        stage = STAGE_NEED;
-      } else {
-        inv_d = rt::ray_inv_dir(ps.ray);
-        dir_neg = rt::ray_dir_neg(ps.ray);
-        best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
-        stack.reset();
-        node = root;
-      }
-    }
-    // ---- exit: nothing walking, nothing to shade, queue drained
-    unsigned long long walk_mask = wave_ballot(stage == STAGE_WALK);
-    if (walk_mask == 0ull) {
-      if (queue_empty && wave_ballot(stage != STAGE_NEED) == 0ull) break;
-      continue;  // lanes whose path ended in 1c: go regenerate
-    }
-    // ---- phase 2: node steps while enough lanes walk
-    const uint32_t threshold = queue_empty ? 1u : walk_threshold;
-    do {
-      if (stage == STAGE_WALK) {
-        if (!rt::bvh_step<F, false>(sv, first_ref, ps.ray, inv_d, dir_neg, 0.001, &node, &best, stack, nullptr)) {
-          stage = STAGE_SHADE;
-          node = -1;  // the next ray of this lane starts a new bounce
-        }
-      }
-      walk_mask = wave_ballot(stage == STAGE_WALK);
-    } while ((uint32_t)__popcll(walk_mask) >= threshold);
-  }
-}
-
-// ---- wave-synchronous BVH walk with deferred leaves --------------------------------------------
-// In bvh_step a leaf child is intersected inline, i.e. inside a branch only the lanes that reached
-// a leaf take, while the rest of the wave waits -- on every step.  Here a leaf is just another work
-// item: an item is a node (code >= 0) or a leaf (code < 0); a node step tests the node's two child
-// boxes and only QUEUES hit children (near one becomes the current item, far one goes on the LDS
-// stack), a leaf step intersects the leaf's primitives.  Each iteration the wave votes (__ballot)
-// and runs the kind of step most of its lanes are waiting for, so both bodies run well filled.
-// Visiting order differs from bvh_step; the closest hit (with its tie rule) does not.
-#define WALK_DONE 0x7fffffff
-template <uint32_t F>
-__device__ __forceinline__ void walk_node_step(const rt::SceneView& sv, const rt::Ray& r, rt::Vec3 inv_d,
-                                               uint32_t dir_neg, double t_min, double best_t,
-                                               int32_t* cur, LdsStack& stack) {
-  const rt::FlatNode& n = sv.nodes[*cur];
-  int first = (int)((dir_neg >> (uint32_t)n.pad[0]) & 1u);
-  bool hf = rt::aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best_t);
-  bool hs = rt::aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best_t);
-  int32_t cf = n.child[first], cs = n.child[1 - first];
-  if (hf) {
-    *cur = cf;
-    if (hs) stack.push(cs);
-  } else if (hs) {
-    *cur = cs;
-  } else {
-    *cur = stack.empty() ? WALK_DONE : stack.pop();
-  }
-}
-// Node step on the f32 culling tree (core/cull32.hpp): cheaper per step (2-cycle f32 issue, 64-B
-// node) and, being conservative, invisible in the result.
-template <class STACK>
-__device__ __forceinline__ void walk_node_step32(const rt::FlatNode32& n, const rt::Ray32& q, uint32_t dir_neg,
-                                                 float t_max32, int32_t* cur, STACK& stack) {
-  int first = (int)((dir_neg >> (uint32_t)n.axis) & 1u);
-  bool hf, hs;
-  rt::cull32_may_hit2(n.lo[first], n.hi[first], n.lo[1 - first], n.hi[1 - first], q, t_max32, &hf, &hs);
-  int32_t cf = n.child[first], cs = n.child[1 - first];
-  if (hf) {
-    *cur = cf;
-    if (hs) stack.push(cs);
-  } else if (hs) {
-    *cur = cs;
-  } else {
-    *cur = stack.empty() ? WALK_DONE : stack.pop();
-  }
-}
-// tri_base >= 0: the BVH holds triangles only and slot s is triangle tri_base + s (the flattener stores a mesh's
-// triangles in leaf order), so the primitive reference need not be fetched.
-template <uint32_t F>
-__device__ __forceinline__ void walk_leaf_step(const rt::SceneView& sv, uint32_t first_ref, const rt::Ray& r,
-                                               double t_min, rt::Closest* best, int32_t* cur, LdsStack& stack,
-                                               int32_t tri_base = -1) {
-  uint32_t f = rt::leaf_first(*cur), k = rt::leaf_count(*cur);
-  for (uint32_t i = 0; i < k; ++i) {
-    const rt::PrimRef ref = ((F & rt::F_TRIANGLE) && tri_base >= 0)
-                                ? rt::make_primref(rt::PRIM_TRIANGLE, (uint32_t)tri_base + f + i)
-                                : sv.refs[first_ref + f + i];
-    rt::offer_prim<F, false>(sv, ref, f + i, r, t_min, best, nullptr);
-  }
-  *cur = stack.empty() ? WALK_DONE : stack.pop();
-}
-
-// ------------------------------------------------------------------ 4-wide culling tree (big meshes)
-// On the dragon room the walk is bound by the latency of dependent node fetches (28 MB of culling tree: every step
-// waits for L2 / MALL), not by VALU.  A 4-wide tree halves the length of that chain: built at upload by collapsing the
-// binary SAH tree (the child with the largest area is opened until four slots are used), one 128-byte record = one
-// cache line per step, boxes rounded outward to f32 exactly like FlatNode32.  Wide node i is binary node i opened
-// up, so child codes (node index >= 0, leaf code < 0) are the binary tree's and leaves are untouched.  Culling
-// structure only: every hit is still decided by the f64 primitive tests, so results do not change.
-struct FlatNode4 {  // 128 B, field-major so that one child's six planes are six scalar picks from float4 loads
-  float lo[3][4];
-  float hi[3][4];
-  int32_t child[4];  // WALK_DONE marks an empty slot (its box is empty too)
-  int32_t pad[4];
-};
-static_assert(sizeof(FlatNode4) == 128, "one cache line per wide node");
-
-// Host: collapse fs.nodes below `root` into `out` (indexed like fs.nodes); returns the peak stack use of a walk.
-static int build_wide_nodes(const std::vector<rt::FlatNode>& nodes, int32_t root, std::vector<FlatNode4>* out) {
-  struct Slot { int32_t code; double mn[3], mx[3]; };
-  auto half_area = [](const Slot& s) {
-    double dx = s.mx[0] - s.mn[0], dy = s.mx[1] - s.mn[1], dz = s.mx[2] - s.mn[2];
-    return dx * dy + dy * dz + dz * dx;
-  };
-  auto slots_of = [&](int32_t n, Slot* dst) {
-    for (int c = 0; c < 2; ++c) {
-      dst[c].code = nodes[n].child[c];
-      for (int a = 0; a < 3; ++a) { dst[c].mn[a] = nodes[n].bmin[c][a]; dst[c].mx[a] = nodes[n].bmax[c][a]; }
-    }
-  };
-  struct Frame { int32_t node; int next; int nslots; int32_t kids[4]; int peak_kids; };
-  std::vector<Frame> stack;
-  std::vector<int> peak(nodes.size(), 0);
-  auto open = [&](int32_t n) {
-    Slot sl[4];
-    int ns = 2;
-    slots_of(n, sl);
-    while (ns < 4) {
-      int best = -1;
-      double best_area = -1.0;
-      for (int k = 0; k < ns; ++k)
-        if (sl[k].code >= 0 && half_area(sl[k]) > best_area) { best_area = half_area(sl[k]); best = k; }
-      if (best < 0) break;
-      Slot two[2];
-      slots_of(sl[best].code, two);
-      sl[best] = two[0];
-      sl[ns++] = two[1];
-    }
-    FlatNode4& w = (*out)[n];
-    Frame f;
-    f.node = n; f.next = 0; f.nslots = ns; f.peak_kids = 0;
-    for (int k = 0; k < 4; ++k) {
-      f.kids[k] = -1;
-      if (k < ns) {
-        for (int a = 0; a < 3; ++a) {
-          float lo = (float)sl[k].mn[a];
-          if ((double)lo > sl[k].mn[a]) lo = std::nextafterf(lo, -INFINITY);
-          float hi = (float)sl[k].mx[a];
-          if ((double)hi < sl[k].mx[a]) hi = std::nextafterf(hi, INFINITY);
-          w.lo[a][k] = lo; w.hi[a][k] = hi;
-        }
-        w.child[k] = sl[k].code;
-        if (sl[k].code >= 0) f.kids[k] = sl[k].code;
-      } else {
-        for (int a = 0; a < 3; ++a) { w.lo[a][k] = INFINITY; w.hi[a][k] = -INFINITY; }
-        w.child[k] = 0x7fffffff;
-      }
-      w.pad[k] = 0;
-    }
-    stack.push_back(f);
-  };
-  open(root);
-  while (!stack.empty()) {
-    Frame& f = stack.back();
-    if (f.next < 4) {
-      int32_t kid = f.kids[f.next++];
-      if (kid >= 0) open(kid);
-      continue;
-    }
-    // all wide children done: a walk pushes up to nslots items here, pops one and descends with nslots - 1 left
-    int pk = f.nslots;
-    for (int k = 0; k < 4; ++k)
-      if (f.kids[k] >= 0) pk = std::max(pk, f.nslots - 1 + peak[f.kids[k]]);
-    peak[f.node] = pk;
-    stack.pop_back();
-  }
-  return peak[root];
-}
-
-// One wide step: test the four child boxes, push the hit ones so that the nearest ends on top, pop it.
-__device__ __forceinline__ bool slab_interval(float lx, float ly, float lz, float hx, float hy, float hz, const rt::Ray32& q,
-                                              float t_max32, float* t_near) {
-  float ax = __builtin_fmaf(lx, q.ix, -q.oix), bx = __builtin_fmaf(hx, q.ix, -q.oix);
-  float ay = __builtin_fmaf(ly, q.iy, -q.oiy), by = __builtin_fmaf(hy, q.iy, -q.oiy);
-  float az = __builtin_fmaf(lz, q.iz, -q.oiz), bz = __builtin_fmaf(hz, q.iz, -q.oiz);
-  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                             __builtin_fmaxf(__builtin_fminf(az, bz), q.t_min));
-  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                             __builtin_fminf(__builtin_fmaxf(az, bz), t_max32));
-  *t_near = tn;
-  return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));  // as cull32_may_hit
-}
-__device__ __forceinline__ void walk_node_step4(const FlatNode4* __restrict__ nodes4, const rt::Ray32& q, float t_max32,
-                                                int32_t* cur, LdsStack& stack) {
-  const float4* p = (const float4*)&nodes4[*cur];
-  const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
-  const int4 ch = *(const int4*)&nodes4[*cur].child[0];
-  float k0, k1, k2, k3;
-  const bool h0 = slab_interval(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, q, t_max32, &k0) && ch.x != WALK_DONE;
-  const bool h1 = slab_interval(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, q, t_max32, &k1) && ch.y != WALK_DONE;
-  const bool h2 = slab_interval(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, q, t_max32, &k2) && ch.z != WALK_DONE;
-  const bool h3 = slab_interval(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, q, t_max32, &k3) && ch.w != WALK_DONE;
-  const float inf = __builtin_huge_valf();
-  k0 = h0 ? k0 : inf; k1 = h1 ? k1 : inf; k2 = h2 ? k2 : inf; k3 = h3 ? k3 : inf;
-  // rank = number of children that come before this one (ties: lower slot first); hits rank 0 .. nh-1
-  const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
-  const int r0 = b10 + b20 + b30;
-  const int r1 = (1 - b10) + b21 + b31;
-  const int r2 = (1 - b20) + (1 - b21) + b32;
-  const int r3 = (1 - b30) + (1 - b31) + (1 - b32);
-  const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-  const int top = stack.n + nh - 1;  // the nearest hit goes here
-  if (h0) stack.base[(top - r0) * TRACE_BLOCK] = ch.x;
-  if (h1) stack.base[(top - r1) * TRACE_BLOCK] = ch.y;
-  if (h2) stack.base[(top - r2) * TRACE_BLOCK] = ch.z;
-  if (h3) stack.base[(top - r3) * TRACE_BLOCK] = ch.w;
-  stack.n += nh;
-  *cur = stack.empty() ? WALK_DONE : stack.pop();
-}
-
-// The voting walk as a world_hit walker policy (core/geometry.hpp): every lane that reaches a BVH
-// entry walks it together with the rest of its wave.  Top-level entry kinds are the same for all
-// lanes, so the enclosing control flow is wave-uniform up to lanes that already missed.
-template <bool WIDE>
-struct VoteWalkT {
-  template <uint32_t F, bool COUNT, class STACK>
-  __device__ __forceinline__ static void run(const rt::SceneView& sv, int32_t root, uint32_t first_ref,
-                                             const rt::Ray& r, double t_min, rt::Closest* best, STACK& stack,
-                                             rt::TraceCounters*) {
-    rt::Ray32 q = rt::make_ray32(r, t_min);
-    uint32_t dir_neg = rt::ray_dir_neg(r);
-    float t_max32 = rt::cull_round_up(best->t);
-    stack.reset();
-    int32_t cur = root;
-    const uint32_t leaf_weight = sv.pad ? sv.pad : 3u;  // the launcher passes the vote weight in SceneView.pad
-    for (;;) {
-      bool is_leaf = cur < 0;
-      bool is_node = !is_leaf && cur != WALK_DONE;
-      unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
-      if ((m_node | m_leaf) == 0ull) break;
-      if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
-        if (is_node) {
-          if (WIDE) walk_node_step4((const FlatNode4*)sv.nodes, q, t_max32, &cur, stack);
-          else walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
-        }
-      } else {
-        if (is_leaf) {
-          walk_leaf_step<F>(sv, first_ref, r, t_min, best, &cur, stack);
-          t_max32 = rt::cull_round_up(best->t);
-        }
-      }
-    }
-  }
-};
-
-// k_trace_persistent with the deferred-leaf walk, for worlds that are one BVH.
-// DIAG: per-region occupancy counters (diag[2k] = times the wave executed region k, diag[2k+1] = lanes
-// active in it); regions: 0 outer iteration, 1 regenerate, 2 node step, 3 leaf step, 4 shade (hit lanes),
-// 5 shade (all walking lanes).  Diagnostic build only (RTX_TRACE_KERNEL=vote_diag); never timed.
-//
-// RING: primary rays are produced 64 at a time.  Regeneration (Philox seeding, pixel jitter, lens
-// rejection loop, camera ray: ~600 VALU) used to run every outer iteration for just the ~20 lanes
-// whose path had ended.  With RING a wave keeps up to 64 ready primary rays (ray + RNG state + sample
-// index, 76 B each) in its own slice of LDS; a lane whose path ends pops one (10 LDS reads), and only
-// when the ring cannot serve the request does the whole wave run the regeneration code, all lanes at
-// once, to top the ring up.  Which lane traces a sample is invisible in the result.
-#define RING_F64 9  // origin(3) direction(3) time rng.s0 rng.s1
-#define RING_BYTES_PER_WAVE (64u * (RING_F64 * 8u + 4u))
-template <uint32_t F, bool DIAG, bool RING, bool WIDE>
-__global__ __launch_bounds__(TRACE_BLOCK, 4) void k_trace_vote(rt::SceneView sv, rt::RenderParams rp,
-                                                            ShardMap sm, uint32_t s_begin, uint32_t total,
-                                                            uint32_t npix, double* __restrict__ samples,
-                                                            unsigned int* work_counter,
-                                                            unsigned long long* diag, uint32_t leaf_weight,
-                                                            uint32_t walk_threshold, uint32_t stack_levels, uint32_t bvh_pos,
-                                                            const FlatNode4* __restrict__ nodes4, int32_t tri_base) {
-  unsigned long long dg[12];
-  if (DIAG) for (int k = 0; k < 12; ++k) dg[k] = 0;
-#define DIAG_ADD(region, mask) do { if (DIAG) { dg[2 * (region)] += 1; dg[2 * (region) + 1] += (unsigned long long)__popcll(mask); } } while (0)
-  extern __shared__ int32_t lds_stack[];
-  LdsStack stack;
-  stack.base = lds_stack + threadIdx.x;
-  stack.n = 0;
-  const uint32_t lane = threadIdx.x & 63u;
-  // this wave's ring of ready primary rays: f64 [RING_F64][64], then u32 [64] (sample index)
-  double* const ring_f = (double*)((unsigned char*)(lds_stack + stack_levels * TRACE_BLOCK) +
-                                   (threadIdx.x >> 6) * RING_BYTES_PER_WAVE);
-  uint32_t* const ring_g = (uint32_t*)(ring_f + RING_F64 * 64);
-  uint32_t ring_n = 0;                    // wave-uniform: entries in the ring (a stack)
-  const rt::FlatEntry& bvh = sv.entries[sv.top_level[bvh_pos]];
-  const int32_t root = bvh.a;
-  const uint32_t first_ref = (uint32_t)bvh.b;
-  uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform
-  bool queue_empty = false;               // wave-uniform
-  bool active = false;
-  uint32_t g = 0;
-  rt::PathState ps;
-  // walk state, kept across outer iterations so an unfinished walk can be carried over
-  bool midwalk = false;
-  rt::Ray32 q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  uint32_t dir_neg = 0;
-  float t_max32 = 0.f;
-  int32_t cur = WALK_DONE;
-  rt::Closest best;
-  best.t = 0.0; best.ref = 0; best.order = 0; best.hit = false;
-  for (;;) {
-    unsigned long long need_mask = wave_ballot(!active);
-    if (RING) {
-      if (need_mask != 0ull) {
-        const uint32_t n_need = (uint32_t)__popcll(need_mask);
-        // top the ring up (at most twice: a chunk boundary can cut the first batch short)
-        for (int rep = 0; rep < 2 && ring_n < n_need && !queue_empty; ++rep) {
-          if (chunk_pos >= chunk_end) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= total) { queue_empty = true; break; }
-            chunk_pos = base;
-            chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
-          }
-          const uint32_t room = 64u - ring_n, avail = chunk_end - chunk_pos;
-          const uint32_t m = room < avail ? room : avail;
-          DIAG_ADD(1, wave_ballot(lane < m));
-          if (lane < m) {
-            const uint32_t gg = chunk_pos + lane;
-            uint32_t s_local = gg / npix;
-            uint32_t lp = gg - s_local * npix;
-            uint32_t i, j;
-            shard_pixel(sm, lp, &i, &j);
-            rt::PathState fresh;
-            rt::path_begin(rp, i, j, s_begin + s_local, &fresh);
-            const uint32_t slot = ring_n + lane;
-            ring_f[0 * 64 + slot] = fresh.ray.origin.x; ring_f[1 * 64 + slot] = fresh.ray.origin.y;
-            ring_f[2 * 64 + slot] = fresh.ray.origin.z; ring_f[3 * 64 + slot] = fresh.ray.direction.x;
-            ring_f[4 * 64 + slot] = fresh.ray.direction.y; ring_f[5 * 64 + slot] = fresh.ray.direction.z;
-            ring_f[6 * 64 + slot] = fresh.ray.time;
-            ring_f[7 * 64 + slot] = rt::bits_f64(fresh.rng.s0); ring_f[8 * 64 + slot] = rt::bits_f64(fresh.rng.s1);
-            ring_g[slot] = gg;
-          }
-          chunk_pos += m;
-          ring_n += m;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS executes a wave's accesses in order
-        }
-        const uint32_t take = n_need < ring_n ? n_need : ring_n;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-        if (!active && rank < take) {
-          const uint32_t slot = ring_n - 1u - rank;
-          ps.ray = rt::make_ray(rt::v3(ring_f[0 * 64 + slot], ring_f[1 * 64 + slot], ring_f[2 * 64 + slot]),
-                                rt::v3(ring_f[3 * 64 + slot], ring_f[4 * 64 + slot], ring_f[5 * 64 + slot]),
-                                ring_f[6 * 64 + slot]);
-          ps.rng.s0 = rt::f64_bits(ring_f[7 * 64 + slot]); ps.rng.s1 = rt::f64_bits(ring_f[8 * 64 + slot]);
-          ps.product = rt::v3(1, 1, 1);   // path_begin's constants (core/integrator.hpp)
-          ps.output = rt::v3(0, 0, 0);
-          ps.depth = rp.max_depth;
-          g = ring_g[slot];
-          active = true;
-        }
-        ring_n -= take;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
-    } else if (need_mask != 0ull) {
-      if (chunk_pos >= chunk_end && !queue_empty) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(work_counter, TRACE_CHUNK);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= total) {
-          queue_empty = true;
-        } else {
-          chunk_pos = base;
-          chunk_end = (total - base < TRACE_CHUNK) ? total : base + TRACE_CHUNK;
-        }
-      }
-      if (chunk_pos < chunk_end) {
-        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-        uint32_t n_need = (uint32_t)__popcll(need_mask);
-        uint32_t avail = chunk_end - chunk_pos;
-        DIAG_ADD(1, wave_ballot(!active && rank < avail));
-        if (!active && rank < avail) {
-          g = chunk_pos + rank;
-          uint32_t s_local = g / npix;
-          uint32_t lp = g - s_local * npix;
-          uint32_t i, j;
-          shard_pixel(sm, lp, &i, &j);
-          rt::path_begin(rp, i, j, s_begin + s_local, &ps);
-          active = true;
-        }
-        chunk_pos += (n_need < avail) ? n_need : avail;
-      }
-    }
-    if (wave_ballot(active) == 0ull) break;
-    DIAG_ADD(0, wave_ballot(active));
-    // ---- begin a bounce for every lane that is not in the middle of a carried-over walk
-    if (active && !midwalk) {
-      if (rt::path_bounce_begin(&ps)) {
-        double* o = samples + 3 * (size_t)g;
-        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
-        active = false;
-      } else {
-        q = rt::make_ray32(ps.ray, 0.001);
-        dir_neg = rt::ray_dir_neg(ps.ray);
-        t_max32 = __builtin_huge_valf();
-        best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
-        stack.reset();
-        cur = root;
-        midwalk = true;
-      }
-    }
-    // ---- walk: cost-weighted node/leaf vote.  The loop stops as soon as fewer than `walk_threshold`
-    // lanes are still walking: the stragglers keep their walk state and continue next round, so the
-    // wave never waits for the longest walk of a bounce (all remaining ones once the queue is empty).
-    const uint32_t threshold = (queue_empty && ring_n == 0u) ? 1u : walk_threshold;
-    for (;;) {
-      // cur == WALK_DONE whenever a lane is not in a walk, so the item alone tells the lane's state
-      bool is_leaf = cur < 0;
-      bool is_node = (uint32_t)cur < (uint32_t)WALK_DONE;
-      unsigned long long m_node = wave_ballot(is_node), m_leaf = wave_ballot(is_leaf);
-      if ((uint32_t)__popcll(m_node | m_leaf) < threshold) break;
-      if ((uint32_t)__popcll(m_node) * leaf_weight >= (uint32_t)__popcll(m_leaf)) {
-        DIAG_ADD(2, m_node);
-        if (is_node) {
-          if (WIDE) walk_node_step4(nodes4, q, t_max32, &cur, stack);
-          else walk_node_step32(sv.nodes32[cur], q, dir_neg, t_max32, &cur, stack);
-        }
-      } else {
-        DIAG_ADD(3, m_leaf);
-        if (is_leaf) {
-          walk_leaf_step<F>(sv, first_ref, ps.ray, 0.001, &best, &cur, stack, tri_base);
-          t_max32 = rt::cull_round_up(best.t);
-        }
-      }
-    }
-    // ---- shade the lanes whose walk is complete
-    const bool finished = midwalk && cur == WALK_DONE;
-    DIAG_ADD(4, wave_ballot(finished && best.hit));
-    DIAG_ADD(5, wave_ballot(finished));
-    if (finished) {
-      midwalk = false;
-      if (F & rt::F_PRIM_ENTRY) {
-        // Plain primitives beside the BVH in the top-level list (the dragon room's seven rectangles): tested here,
-        // after the walk, in list order.  HittableList::hit (hit.rs:660-690) lets the LATER entry win an exact
-        // tie, wherever the BVH sits in the list; everything else about a closest hit is order independent.
-        int32_t win_entry = best.hit ? (int32_t)bvh_pos : -1;
-        for (int32_t k = 0; k < sv.n_top_level; ++k) {
-          if (k == (int32_t)bvh_pos) continue;
-          const rt::FlatEntry* e = &sv.entries[dev_load_uniform(&sv.top_level[k])];
-          const rt::PrimRef ref = (rt::PrimRef)dev_load_uniform(&e->a);
-          double t;
-          if (rt::prim_t<F, false>(sv, ref, ps.ray, 0.001, best.t, &t, nullptr)) {
-            if (t < best.t || win_entry < k) { best.t = t; best.ref = ref; best.hit = true; win_entry = k; }
-          }
-        }
-      }
-      rt::HitRecord rec;
-      if (best.hit) rt::prim_finalize<F>(sv, best.ref, ps.ray, best.t, &rec);
-      if (rt::path_bounce_end<F, false>(sv, rp, &ps, best.hit, rec, nullptr)) {
-        double* o = samples + 3 * (size_t)g;
-        o[0] = ps.output.x; o[1] = ps.output.y; o[2] = ps.output.z;
-        active = false;
-      }
-    }
-  }
-  if (DIAG) {
-    if (lane == 0)
-      for (int k = 0; k < 12; ++k) atomicAdd(&diag[k], dg[k]);
-  }
-#undef DIAG_ADD
-}
-
-#include "trace_wq.inc"
-#include "trace_lds.inc"
-
-// One lane per pixel; samples of the pass are added in ascending sample index.
-__global__ __launch_bounds__(256) void k_reduce_samples(const double* __restrict__ samples,
-                                                        double* __restrict__ accum, uint32_t npix,
-                                                        uint32_t s_count, int first_pass) {
-  uint32_t lp = blockIdx.x * 256u + threadIdx.x;
-  if (lp >= npix) return;
-  double r = 0.0, g = 0.0, b = 0.0;  // world.rs:1210: Vec3::new(0, 0, 0)
-  if (!first_pass) { r = accum[3 * (size_t)lp]; g = accum[3 * (size_t)lp + 1]; b = accum[3 * (size_t)lp + 2]; }
-  for (uint32_t s = 0; s < s_count; ++s) {
-    const double* p = samples + 3 * ((size_t)s * npix + lp);
-    r += p[0]; g += p[1]; b += p[2];  // world.rs:1215 (vec3.rs:223-229 AddAssign)
-  }
-  accum[3 * (size_t)lp] = r; accum[3 * (size_t)lp + 1] = g; accum[3 * (size_t)lp + 2] = b;
-}
-
-__global__ __launch_bounds__(256) void k_tonemap(const double* __restrict__ accum,
-                                                 uint8_t* __restrict__ rgb8, uint32_t npix,
-                                                 uint32_t spp) {
-  uint32_t lp = blockIdx.x * 256u + threadIdx.x;
-  if (lp >= npix) return;
-  int32_t c[3];
-  rt::tone_map(rt::v3(accum[3 * (size_t)lp], accum[3 * (size_t)lp + 1], accum[3 * (size_t)lp + 2]), spp, c);
-  rgb8[3 * (size_t)lp] = (uint8_t)c[0];
-  rgb8[3 * (size_t)lp + 1] = (uint8_t)c[1];
-  rgb8[3 * (size_t)lp + 2] = (uint8_t)c[2];
-}
-
-// Device self-test kernels (rtx_device_math / rtx_device_stream).
-__global__ void k_device_math(int fn, const double* x, const double* y, long long n, double* out) {
-  long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  double a = x[k], b = y[k], r;
-  switch (fn) {
-    case 0: r = rt::rt_sin(a); break;
-    case 1: r = rt::rt_cos(a); break;
-    case 2: r = rt::rt_log(a); break;
-    case 3: r = rt::rt_acos(a); break;
-    case 4: r = rt::rt_atan2(a, b); break;
-    case 5: r = rt::rt_tan(a); break;
-    case 6: r = rt::rt_sqrt(a); break;
-    case 7: r = a / b; break;
-    case 8: r = a * b + a; break;
-    default: r = rt::rt_floor(a); break;
-  }
-  out[k] = r;
-}
-__global__ void k_device_stream(unsigned long long seed, unsigned long long pixel, unsigned int sample, int n, double* out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  rt::Rng g = rt::rng_for_sample(seed, pixel, sample);
-  for (int k = 0; k < n; ++k) out[k] = rt::rng_f64(g);
-}
+#include "trace_basic.inc"   // k_trace_simple, k_trace_persistent, k_trace_stream
+#include "trace_vote.inc"    // voting walk, 4-wide tree, k_trace_vote
+#include "trace_wq.inc"      // k_trace_wq (experimental)
+#include "trace_lds.inc"     // k_trace_lds (the headline kernel)
+#include "post_kernels.inc"  // k_reduce_samples, k_tonemap, device self tests
 
 // ------------------------------------------------------------------ launcher
 static int shard_row_count(int32_t height, const RtxShard& sh, int32_t row_limit) {
