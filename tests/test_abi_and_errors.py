@@ -114,12 +114,22 @@ def test_no_cpu_fallback_without_gpu(rtsr):
     assert e.value.status == rtsr.RTX_EHIP
 
 
+def test_trace_kernel_names(rtsr):
+    """RtxRenderStats.trace_kernel ids map to the kernel names rocprofv3 prints."""
+    names = [rtsr.trace_kernel_name(k) for k in range(6)]
+    assert names == ["k_trace_simple", "k_trace_persistent", "k_trace_stream", "k_trace_vote", "k_trace_lds", "k_trace_wq"]
+    assert rtsr.trace_kernel_name(99) == "?"
+    for n in names:  # every reported name is a kernel that exists in the sources
+        assert any(n in open(os.path.join(ROOT, "ray-tracing-series-rust_amd", "csrc", "hip", f)).read()
+                   for f in os.listdir(os.path.join(ROOT, "ray-tracing-series-rust_amd", "csrc", "hip")) if f.endswith((".hip", ".inc")))
+
+
 def test_product_never_touches_the_oracle():
     """oracle/ is test infrastructure: nothing under the product package may reference it."""
     pkg = os.path.join(ROOT, "ray-tracing-series-rust_amd")
     for base, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", ".inc")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 for line in text.splitlines():
                     code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
