@@ -213,6 +213,7 @@ void oracle_rt_math(int32_t fn, const double* x, const double* y, int64_t n, dou
       case 3: out[k] = rt::rt_acos(x[k]); break;
       case 4: out[k] = rt::rt_atan2(x[k], y[k]); break;
       case 5: out[k] = rt::rt_tan(x[k]); break;
+      case 10: out[k] = (double)rt::rt_sin_sign(x[k]); break;
       default: out[k] = rt::rt_sqrt(x[k]); break;
     }
   }

@@ -162,7 +162,7 @@ def o2_sample(flat_arrays_ptr, rtx_cam, rtx_cfg, image_height, i, j, s):
 
 def rt_math(fn, x, y=None):
     lib = load()
-    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6}
+    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6, "sin_sign": 10}
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
     out = np.empty_like(x)

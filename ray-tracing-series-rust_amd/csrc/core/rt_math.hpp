@@ -100,6 +100,25 @@ RT_HD double rt_cos(double x) {
   }
 }
 
+// The SIGN of rt_sin(x) without evaluating the polynomials: -1, 0, +1, or 2 when rt_sin(x) is NaN.  Exact, not an
+// approximation: on the reduced range k_cos is positive (>= 0.7), and k_sin(y0, y1) = y0 - (terms smaller than |y0|),
+// so it has the sign of y0 (of the tail y1 in the unreachable case y0 == 0); the quadrant does the rest.  The checker
+// texture (texture.rs:56-62) only asks whether sin(10x) sin(10y) sin(10z) < 0 -- a product of three factors no smaller
+// than ~1e-19 each cannot underflow, so its sign is the product of these signs.
+RT_HD int rt_sin_sign(double x) {
+  if (!(rt_fabs(x) <= 1.0e300)) return (x - x == 0.0) ? 0 : 2;  // rt_sin returns x - x there: 0 if finite, else NaN
+  if (rt_fabs(x) <= 0.78539816339744830962) return x > 0.0 ? 1 : (x < 0.0 ? -1 : 0);
+  double y0, y1;
+  int n = detail::rem_pio2(x, &y0, &y1);
+  int s = y0 > 0.0 ? 1 : (y0 < 0.0 ? -1 : (y1 > 0.0 ? 1 : (y1 < 0.0 ? -1 : 0)));
+  switch (n & 3) {
+    case 0: return s;
+    case 1: return 1;
+    case 2: return -s;
+    default: return -1;
+  }
+}
+
 // Host-only use (Camera::new); quotient of the two kernels above.
 RT_HD double rt_tan(double x) { return rt_sin(x) / rt_cos(x); }
 

@@ -126,8 +126,11 @@ RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, 
     for (int guard = 0; guard < 16; ++guard) {
       const FlatTexture& t = sv.textures[tex];
       if (t.kind != TEX_CHECKER) break;
-      double sines = rt_sin(10.0 * p.x) * rt_sin(10.0 * p.y) * rt_sin(10.0 * p.z);
-      tex = (sines < 0.0) ? t.b : t.a;
+      // texture.rs:56-62: sines = sin(10x) sin(10y) sin(10z); sines < 0 -> odd.  Only the sign is used, and
+      // rt_sin_sign gives exactly the sign rt_sin would have (a NaN or a zero factor makes the test false).
+      int sx = rt_sin_sign(10.0 * p.x), sy = rt_sin_sign(10.0 * p.y), sz = rt_sin_sign(10.0 * p.z);
+      bool negative = sx != 2 && sy != 2 && sz != 2 && sx * sy * sz < 0;
+      tex = negative ? t.b : t.a;
     }
   }
   const FlatTexture& t = sv.textures[tex];

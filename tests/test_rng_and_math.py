@@ -89,3 +89,20 @@ def test_rt_math_special_values(orc):
     assert orc.rt_math("atan2", [1.0], [0.0])[0] == np.pi / 2
     assert orc.rt_math("sin", [0.0])[0] == 0.0 and orc.rt_math("cos", [0.0])[0] == 1.0
     assert np.isnan(orc.rt_math("sin", [inf])[0]) and np.isnan(orc.rt_math("cos", [nan])[0])
+
+
+def test_sign_of_sine_is_exact(orc):
+    """rt_sin_sign (the checker texture's sign test without the polynomials) must equal the sign of rt_sin
+    everywhere, including next to multiples of pi/2, at zero, and for non-finite input (2 = NaN)."""
+    rng = np.random.default_rng(11)
+    k = rng.integers(-200000, 200000, 400000).astype(np.float64)
+    near = k * (np.pi / 2)
+    near = np.concatenate([near, np.nextafter(near, np.inf), np.nextafter(near, -np.inf),
+                           near * (1 + rng.uniform(-1e-12, 1e-12, near.size))])
+    x = np.concatenate([rng.uniform(-1, 1, 200000), rng.uniform(-60000, 60000, 400000), near,
+                        [0.0, -0.0, 1e-300, -1e-300, 0.7853981633974483, -0.7853981633974483, 1.5e6, -1.5e6,
+                         np.inf, -np.inf, np.nan, 1e301]])
+    s = orc.rt_math("sin", x)
+    want = np.where(np.isnan(s), 2.0, np.sign(s))
+    got = orc.rt_math("sin_sign", x)
+    assert np.array_equal(got, want), "%d mismatches" % int((got != want).sum())
