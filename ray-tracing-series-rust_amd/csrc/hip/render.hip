@@ -310,11 +310,13 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring, ds->lds_dims);
         uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
         uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
-#define LAUNCH_LDS(RINGF)                                                                              \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<P_SPHERES, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
+#define LAUNCH_LDS(FEAT, RINGF)                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
                      ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, (uint32_t)stack_levels, ds->lds_dims)
-        if (ds->lds_ring) { LAUNCH_LDS(true); } else { LAUNCH_LDS(false); }
+        // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
+        if ((feat & ~P_STATIC_SPHERES) == 0) { if (ds->lds_ring) { LAUNCH_LDS(P_STATIC_SPHERES, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false); } }
+        else if (ds->lds_ring) { LAUNCH_LDS(P_SPHERES, true); } else { LAUNCH_LDS(P_SPHERES, false); }
 #undef LAUNCH_LDS
       } else if (ds->force_wq && ds->wq_ok && preset == 0) {
         kernel_used = RTX_KERNEL_WQ;
@@ -616,9 +618,10 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         // the limit is a property of the function, not of this scene: raise it to the device maximum once, so that
         // scenes uploaded earlier (with other LDS sizes) keep launching
         const int bytes = lds_max;
-        hipError_t ae = ds->lds_ring
-            ? hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-            : hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipError_t ae = hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_STATIC_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_STATIC_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
       }
       if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring %d, %u B of LDS)\n", ds->lds_ok ? "on" : "off", (int)ds->lds_ring,
