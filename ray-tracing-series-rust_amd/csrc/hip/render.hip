@@ -383,10 +383,14 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
           uint64_t res4 = (uint64_t)ds->n_cu * (uint64_t)ds->wide_blocks_per_cu;
           grid = (uint32_t)(want < res4 ? want : res4);
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
-                             stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
-                             (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
-                             (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base);
+#define LAUNCH_VOTE_WIDE(FEAT)                                                                         \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds, \
+                     stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,  \
+                     (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels, \
+                     (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base)
+          // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
+          if ((feat & ~P_MESH_ROOM) == 0) { LAUNCH_VOTE_WIDE(P_MESH_ROOM); } else { LAUNCH_VOTE_WIDE(P_MESH); }
+#undef LAUNCH_VOTE_WIDE
         }
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
