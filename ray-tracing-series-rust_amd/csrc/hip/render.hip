@@ -66,7 +66,7 @@ struct DeviceScene {
   int32_t vote_bvh_pos = 0;           // position of the BVH entry in the top-level list
   int32_t vote_tri_base = -1;         // >= 0: that BVH is a pure triangle mesh whose slot s is triangle vote_tri_base + s
   int stream_blocks_per_cu[2] = {1, 1};
-  uint32_t walk_threshold = 12;       // RTX_WALK_THRESHOLD (1 = never carry a walk over)
+  uint32_t walk_threshold = 18;       // RTX_WALK_THRESHOLD (1 = never carry a walk over); 18 measured best on C2 (12..22 within 1 %)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
