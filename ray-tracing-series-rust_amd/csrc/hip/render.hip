@@ -70,6 +70,7 @@ struct DeviceScene {
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
+  uint32_t lds_ring_cap = 64;         // entries per wave ring: 64, or 48 / 32 when the scene leaves less LDS
   uint32_t lds_chunk = TRACE_CHUNK_DEFAULT;  // sample indices a wave reserves per grab (RTX_CHUNK)
   LdsSceneDims lds_dims = {0, 0, 0, 0};
   bool force_wq = false;              // RTX_TRACE_KERNEL=wq: workgroup-queue kernel (trace_wq.inc)
@@ -307,13 +308,13 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
       } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream) {
         kernel_used = RTX_KERNEL_LDS;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
-        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring, ds->lds_dims);
+        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims);
         uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
         uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
 #define LAUNCH_LDS(FEAT, RINGF)                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, (uint32_t)stack_levels, ds->lds_dims)
+                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ds->lds_ring_cap, (uint32_t)stack_levels, ds->lds_dims)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
         if ((feat & ~P_STATIC_SPHERES) == 0) { if (ds->lds_ring) { LAUNCH_LDS(P_STATIC_SPHERES, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false); } }
         else if (ds->lds_ring) { LAUNCH_LDS(P_SPHERES, true); } else { LAUNCH_LDS(P_SPHERES, false); }
@@ -615,8 +616,12 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       const char* rg = getenv("RTX_RING");
       const bool want_ring = !(rg && atoi(rg) == 0);
       if (max_count <= 4 && max_end <= LDSK_MAX_SLOTS && !(sl && atoi(sl) == 0) && lds_max > 0) {
-        if (want_ring && ldsk_layout(levels, true, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = true; }
-        else if (ldsk_layout(levels, false, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
+        for (uint32_t cap : {64u, 48u, 32u}) {
+          if (want_ring && !ds->lds_ok && ldsk_layout(levels, cap, ds->lds_dims).total <= (uint32_t)lds_max) {
+            ds->lds_ok = true; ds->lds_ring = true; ds->lds_ring_cap = cap;
+          }
+        }
+        if (!ds->lds_ok && ldsk_layout(levels, 0u, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
       }
       if (ds->lds_ok) {
         // the limit is a property of the function, not of this scene: raise it to the device maximum once, so that
@@ -628,8 +633,8 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_STATIC_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
       }
-      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring %d, %u B of LDS)\n", ds->lds_ok ? "on" : "off", (int)ds->lds_ring,
-                      ldsk_layout(levels, ds->lds_ring, ds->lds_dims).total);
+      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring of %u, %u B of LDS)\n", ds->lds_ok ? "on" : "off",
+                      ds->lds_ring ? ds->lds_ring_cap : 0u, ldsk_layout(levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims).total);
     }
     ds->wq_diag = (k && strcmp(k, "wq_diag") == 0);
     ds->force_wq = ds->wq_diag || (k && strcmp(k, "wq") == 0);
