@@ -158,6 +158,10 @@ struct SceneView {
   const FlatPerlin* perlins;
   const FlatImage* images;
   const double* texels;  // 3 doubles per texel
+  // f32 bounding box (lo xyz, hi xyz; rounded outward) of every top-level slot that is a plain static primitive,
+  // (-inf, +inf) for every other slot: lets the list scan skip a primitive test no lane of the wave can pass
+  // (core/cull32.hpp: conservative, cannot change a result).  May be null.
+  const float* top_box32;
   int32_t n_top_level;
   int32_t max_stack;  // deepest traversal stack any BVH of this scene needs
   uint32_t features;  // Feature bits the scene can reach

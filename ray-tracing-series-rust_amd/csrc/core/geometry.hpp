@@ -18,6 +18,7 @@
 // keep the reference's "later object wins" exactly (hit.rs:676-680).
 #pragma once
 #include "flat_types.hpp"
+#include "cull32.hpp"
 #include "rng.hpp"
 #include "rt_math.hpp"
 
@@ -402,10 +403,22 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
   if (COUNT) cnt->rays++;
   bool hit_anything = false;
   double closest_so_far = t_max;
+  // plain primitives in the list: a conservative f32 box test per lane, and the f64 primitive test is skipped when
+  // no lane of the wave can pass it (most waves never see Book-2's small spheres)
+  const bool cull_prims = (F & F_PRIM_ENTRY) && sv.top_box32 != nullptr;
+  Ray32 q32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cull_prims) q32 = make_ray32(r, t_min);
   for (int32_t i = 0; i < sv.n_top_level; ++i) {
     // the table walk is wave-uniform: entries are fetched once per wave (rt_load_uniform)
     const FlatEntry e_rec = rt_load_uniform(&sv.entries[rt_load_uniform(&sv.top_level[i])]);
     const FlatEntry* e = &e_rec;
+    if (cull_prims && e->kind == ENTRY_PRIM) {
+      const float* bx = sv.top_box32 + 6 * i;
+      const float lo[3] = {rt_load_uniform(bx + 0), rt_load_uniform(bx + 1), rt_load_uniform(bx + 2)};
+      const float hi[3] = {rt_load_uniform(bx + 3), rt_load_uniform(bx + 4), rt_load_uniform(bx + 5)};
+      const bool may = cull32_may_hit(lo, hi, q32, cull_round_up(closest_so_far));
+      if (!RT_WAVE_ANY(may)) continue;
+    }
     const bool is_medium = (F & F_MEDIUM) && e->kind == ENTRY_MEDIUM;
     FlatEntry solid_rec = e_rec;
     if (is_medium) solid_rec = rt_load_uniform(&sv.entries[e->a]);

@@ -40,6 +40,13 @@ template <class T>
 inline T rt_load_uniform(const T* p) { return *p; }
 #endif
 
+// true if the predicate holds for any lane the wave is executing (device) / for this thread (host)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0ull)
+#else
+#define RT_WAVE_ANY(p) (p)
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_DEVICE_CODE 1
 #else

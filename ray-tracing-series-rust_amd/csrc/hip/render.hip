@@ -499,6 +499,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
   UP(spheres, spheres) UP(moving_spheres, moving_spheres) UP(rects, rects) UP(triangles, triangles)
   UP(nodes, nodes) UP(nodes32, nodes32) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
   UP(materials, materials) UP(textures, textures) UP(perlins, perlins) UP(images, images) UP(texels, texels)
+  UP(top_box32, top_box32)
 #undef UP
   v.n_top_level = (int32_t)fs.top_level.size();
   v.max_stack = fs.max_stack;

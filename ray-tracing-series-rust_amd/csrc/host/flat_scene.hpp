@@ -23,6 +23,7 @@ struct FlatScene {
   std::vector<rt::FlatPerlin> perlins;
   std::vector<rt::FlatImage> images;
   std::vector<double> texels;
+  std::vector<float> top_box32;  // 6 per top-level slot (SceneView::top_box32)
   int32_t max_stack = 0;      // deepest BVH (number of stacked far children a walk can hold)
   int32_t n_bvh = 0;
   uint32_t features = 0;      // rt::Feature bits reachable in this scene
@@ -45,6 +46,7 @@ struct FlatScene {
     v.perlins = perlins.data();
     v.images = images.data();
     v.texels = texels.data();
+    v.top_box32 = top_box32.empty() ? nullptr : top_box32.data();
     v.n_top_level = (int32_t)top_level.size();
     v.max_stack = max_stack;
     v.features = features;

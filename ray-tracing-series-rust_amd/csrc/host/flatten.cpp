@@ -357,6 +357,26 @@ struct Flattener {
       else if (t.kind == rt::TEX_IMAGE) f |= rt::F_IMAGE;
     }
     out.features = f;
+    // boxes of the plain static primitives in the top-level list (moving spheres are left unbounded: the camera's
+    // shutter interval is not known here)
+    out.top_box32.assign(6 * out.top_level.size(), 0.0f);
+    for (size_t k = 0; k < out.top_level.size(); ++k) {
+      float* bx = &out.top_box32[6 * k];
+      for (int a = 0; a < 3; ++a) { bx[a] = -INFINITY; bx[3 + a] = INFINITY; }
+      const rt::FlatEntry& e = out.entries[out.top_level[k]];
+      if (e.kind != rt::ENTRY_PRIM) continue;
+      const rt::PrimRef ref = (rt::PrimRef)e.a;
+      if (rt::primref_type(ref) == rt::PRIM_MOVING_SPHERE) continue;
+      double b[6];
+      prim_box(ref, 0.0, 0.0, b);
+      for (int a = 0; a < 3; ++a) {
+        float lo = (float)b[a];
+        if ((double)lo > b[a]) lo = std::nextafterf(lo, -INFINITY);
+        float hi = (float)b[3 + a];
+        if ((double)hi < b[3 + a]) hi = std::nextafterf(hi, INFINITY);
+        if (lo == lo && hi == hi) { bx[a] = lo; bx[3 + a] = hi; }
+      }
+    }
     // f32 culling copy of every node: lo rounded down, hi rounded up
     out.nodes32.resize(out.nodes.size());
     for (size_t i = 0; i < out.nodes.size(); ++i) {
