@@ -121,6 +121,21 @@ def test_other_scene_seeds(rtsr, orc, scene_seed, sid):
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+@pytest.mark.parametrize("width,aspect,spp,depth", [(1, 1.0, 1, 1), (3, 1.5, 7, 2), (5, 0.5, 3, 50), (64, 1.5, 1, 1), (17, 1.5, 65, 3)])
+def test_tiny_frames(rtsr, orc, width, aspect, spp, depth):
+    """Frames smaller than a wave / a workgroup, one sample, depth 1: the persistent LDS kernel's start-up and
+    drain logic (work chunks, the primary-ray ring, the end phase) on next to no work."""
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(100, camera_aspect=aspect)
+    cfg = rtsr.Config.new(aspect, width, spp, depth, 1, seed=21, background=bg)
+    flat = b.flatten(world)
+    h = rtsr.image_height(cfg)
+    screen = flat.upload().render(cam, cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=2)
+    assert np.array_equal(screen.accum, ref_accum)
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+
+
 WIDE_CASES = [  # (name, scene id, width, aspect, spp, options, expected kernel)
     ("dragon_room", 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, "k_trace_vote"),
     ("book2_final", 6, 96, 1.0, 6, {}, "k_trace_persistent"),
