@@ -162,6 +162,10 @@ rtx_status rtx_flatten(const rtx_builder* b, rtx_handle world, const RtxBuildOpt
                        rtx_flat** out);
 void rtx_flat_destroy(rtx_flat* f); /* NULL-safe */
 rtx_status rtx_flat_info(const rtx_flat* f, RtxFlatInfo* out);
+/* Kind of the index-th slot of the flattened world list (HittableList order, hit.rs:650-652): 0 primitive,
+ * 1 ordered group (HittableList / RectPrism), 2 BVH, 3 Translate/RotateY chain, 4 ConstantMedium; -1 = index out
+ * of range.  Inspection only (lets a host check that its scene flattened to the list it built). */
+int32_t rtx_flat_top_level_kind(const rtx_flat* f, int32_t index);
 /* Copies every array to the CURRENT HIP device. */
 rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* s); /* NULL-safe */

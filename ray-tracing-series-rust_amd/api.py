@@ -118,6 +118,7 @@ ABI = {
     "rtx_camera_new": (C.c_int32, [_D3, _D3, _D3] + [C.c_double] * 6 + [C.POINTER(RtxCamera)]),
     "rtx_config_new": (C.c_int32, [C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RtxConfig)]),
     "rtx_image_height": (C.c_int32, [C.POINTER(RtxConfig)]),
+    "rtx_flat_top_level_kind": (C.c_int32, [_VP, C.c_int32]),
     "rtx_get_world_cam": (C.c_int32, [_VP, C.c_int32, C.POINTER(RtxSceneOptions), C.POINTER(_H), C.POINTER(RtxCamera), _D3]),
     "rtx_flatten": (C.c_int32, [_VP, _H, C.POINTER(RtxBuildOptions), C.POINTER(_VP)]),
     "rtx_flat_destroy": (None, [_VP]),
@@ -363,6 +364,11 @@ class Flat:
         info = RtxFlatInfo()
         _check(lib.rtx_flat_info(self._p, C.byref(info)))
         return {n: getattr(info, n) for n, _ in RtxFlatInfo._fields_}
+
+    def top_level_kinds(self):
+        """Entry kinds of the flattened world list, in HittableList order (rtx_flat_top_level_kind)."""
+        n = self.info()["n_top_level"]
+        return [lib.rtx_flat_top_level_kind(self._p, i) for i in range(n)]
 
     def upload(self):
         return Scene(self)

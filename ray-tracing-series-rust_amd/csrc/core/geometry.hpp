@@ -208,8 +208,20 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
 // the node loop: same value every time).  The reference returns false at the
 // first axis where t_max <= t_min; since t_min only grows and t_max only shrinks
 // that is equivalent to testing once after the third axis.
-RT_HD bool aabb_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min,
-                    double t_max) {
+//
+// STRICT = true is Aabb::hit literally (an empty OR single-point interval misses).  The walkers use
+// STRICT = false ("may hit": only a provably empty interval misses), the same rule the f32 culling
+// test applies (core/cull32.hpp).  Why the walkers do not cull on a single-point interval: a box test is
+// an optimisation here, every hit is decided by the primitive tests, and this build tests the box of
+// every LEAF (a node stores its children's boxes) whereas BvhNode::hit (bvh.rs:97-112) only ever tests
+// the union box of two children.  A zero-thickness leaf box -- an axis-aligned triangle, hit.rs:164-177
+// pads nothing -- would be culled by the literal rule for EVERY ray, although the reference hits such a
+// triangle whenever its sibling is not coplanar with it (which of its random trees make it invisible is
+// topology luck, Q7).  With "may hit" the closest hit is the closest primitive hit, independent of tree
+// shape and of which walker (f64 or f32 culling) runs.  tests/test_oracle_pairs.py::test_axis_aligned_triangles.
+template <bool STRICT>
+RT_HD bool aabb_interval(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min,
+                         double t_max) {
   {
     double t0 = (bmin[0] - o.x) * inv_d.x, t1 = (bmax[0] - o.x) * inv_d.x;
     if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
@@ -228,7 +240,13 @@ RT_HD bool aabb_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d
     t_min = t0 > t_min ? t0 : t_min;
     t_max = t1 < t_max ? t1 : t_max;
   }
-  return !(t_max <= t_min);
+  return STRICT ? !(t_max <= t_min) : !(t_max < t_min);
+}
+RT_HD bool aabb_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min, double t_max) {
+  return aabb_interval<true>(bmin, bmax, o, inv_d, t_min, t_max);
+}
+RT_HD bool aabb_may_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min, double t_max) {
+  return aabb_interval<false>(bmin, bmax, o, inv_d, t_min, t_max);
 }
 
 // A traversal's running answer.
@@ -266,7 +284,7 @@ RT_HD bool bvh_step(const SceneView& sv, uint32_t first_ref, const Ray& r, Vec3 
   const FlatNode& n = sv.nodes[*node];
   if (COUNT) cnt->box_tests += 2;
   int first = (int)((dir_neg >> (uint32_t)n.pad[0]) & 1u);  // near child along the split axis
-  bool hf = aabb_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best->t);
+  bool hf = aabb_may_hit(n.bmin[first], n.bmax[first], r.origin, inv_d, t_min, best->t);
   int32_t cf = n.child[first];
   int32_t next = -1;
   bool have_next = false;
@@ -280,7 +298,7 @@ RT_HD bool bvh_step(const SceneView& sv, uint32_t first_ref, const Ray& r, Vec3 
     }
   }
   // the far box is tested after the near leaf may have shrunk best->t
-  bool hs = aabb_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best->t);
+  bool hs = aabb_may_hit(n.bmin[1 - first], n.bmax[1 - first], r.origin, inv_d, t_min, best->t);
   int32_t cs = n.child[1 - first];
   if (hs) {
     if (node_child_is_leaf(cs)) {

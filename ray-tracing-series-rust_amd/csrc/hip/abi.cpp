@@ -210,6 +210,11 @@ rtx_status rtx_flat_info(const rtx_flat* f, RtxFlatInfo* o) {
   return RTX_OK;
 }
 
+int32_t rtx_flat_top_level_kind(const rtx_flat* f, int32_t index) {
+  if (!f || index < 0 || (size_t)index >= f->scene.top_level.size()) return -1;
+  return f->scene.entries[f->scene.top_level[index]].kind;
+}
+
 // screen.rs:40-59 + vec3.rs:109-114: integer-valued channels printed without a decimal point.
 rtx_status rtx_write_ppm(const char* path, int32_t width, int32_t height, const uint8_t* rgb8) {
   if (width <= 0 || height <= 0 || !rgb8) { set_error("rtx_write_ppm: bad argument"); return RTX_EINVAL; }

@@ -38,9 +38,11 @@ struct Flattener {
   BuildOptions opt;
   std::string err;
   std::vector<int64_t> prim_of;  // graph hittable -> PrimRef already emitted (-1: not yet)
+  std::vector<int32_t> bvh_entry_of;  // graph BVH hittable -> its entry (-1: not yet): a reused handle (the reference holds
+                                      // objects as Arc, so one BvhNode may sit under several Translates) is emitted once
 
   Flattener(const SceneGraph& gg, FlatScene& o, const BuildOptions& op)
-      : g(gg), out(o), opt(op), prim_of(gg.hittables.size(), -1) {}
+      : g(gg), out(o), opt(op), prim_of(gg.hittables.size(), -1), bvh_entry_of(gg.hittables.size(), -1) {}
 
   bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
 
@@ -104,15 +106,16 @@ struct Flattener {
     refs->push_back(emit_rect(rt::RECT_YZ, p0[1], p1[1], p0[2], p1[2], p0[0], o.mat));
   }
 
-  // Primitives of h in list order; lists and prisms are inlined.
-  bool collect_prims(int32_t h, std::vector<rt::PrimRef>* refs, int depth = 0) {
+  // Primitives of h in list order; lists and prisms are inlined.  handles (optional) receives, per reference, the
+  // graph hittable it came from (-1 for the rectangles of a RectPrism, which have no handle of their own).
+  bool collect_prims(int32_t h, std::vector<rt::PrimRef>* refs, int depth = 0, std::vector<int32_t>* handles = nullptr) {
     if (depth > 64) return fail("hittable lists nested deeper than 64");
     const GHittable& o = g.hittables[h];
-    if (is_prim(o.kind)) { refs->push_back(emit_prim(h)); return true; }
-    if (o.kind == H_RECT_PRISM) { emit_prism(o, refs); return true; }
+    if (is_prim(o.kind)) { refs->push_back(emit_prim(h)); if (handles) handles->push_back(h); return true; }
+    if (o.kind == H_RECT_PRISM) { emit_prism(o, refs); if (handles) handles->resize(refs->size(), -1); return true; }
     if (o.kind == H_LIST) {
       for (int32_t c : o.children)
-        if (!collect_prims(c, refs, depth + 1)) return false;
+        if (!collect_prims(c, refs, depth + 1, handles)) return false;
       return true;
     }
     return fail("unsupported nesting: only primitives, RectPrism and lists of those may sit inside a BVH or a transformed/medium list");
@@ -190,10 +193,13 @@ struct Flattener {
       return emit_group(refs);
     }
     if (o.kind == H_BVH) {
+      if (bvh_entry_of[h] >= 0) return bvh_entry_of[h];
       std::vector<rt::PrimRef> refs;
+      std::vector<int32_t> handles;
+      const size_t tris_before = out.triangles.size();  // triangles below this index are referenced by something else already
       for (int32_t c : o.children)
-        if (!collect_prims(c, &refs)) return -1;
-      if (refs.size() < 2 && !opt.reference_bvh) return emit_group(refs);
+        if (!collect_prims(c, &refs, 0, &handles)) return -1;
+      if (refs.size() < 2 && !opt.reference_bvh) return bvh_entry_of[h] = emit_group(refs);
       std::vector<double> boxes(6 * refs.size());
       for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], o.f[0], o.f[1], &boxes[6 * i]);
       std::vector<uint32_t> order;
@@ -218,28 +224,49 @@ struct Flattener {
       e.a = root;
       e.b = (int32_t)out.refs.size();
       e.c = (int32_t)refs.size();
-      // Triangles of this BVH are permuted (within the set of array slots they already occupy) so that array order
-      // is leaf order: a leaf's triangles become neighbours in memory, and for a pure mesh the slot of a reference
-      // is its triangle index minus a constant, which lets the mesh kernels skip the reference fetch.
+      // Triangles of this BVH are stored so that array order is leaf order: a leaf's triangles become neighbours in
+      // memory, and for a pure mesh the slot of a reference is its triangle index minus a constant, which lets the
+      // mesh kernels skip the reference fetch.  Only triangles nothing else refers to may be MOVED for that:
+      //   * every triangle of this BVH was first emitted by this BVH, each once (the catalogue's meshes): they are
+      //     permuted within the slots they occupy, and prim_of follows them so later users of a handle see the move;
+      //   * otherwise (a triangle shared with an earlier entry or BVH, or listed twice) nothing is moved: the BVH gets
+      //     a private leaf-ordered copy of its triangles at the end of the array.
       {
         std::vector<uint32_t> in_leaf_order;
         for (size_t i = 0; i < refs.size(); ++i)
           if (rt::primref_type(refs[order[i]]) == rt::PRIM_TRIANGLE) in_leaf_order.push_back(rt::primref_index(refs[order[i]]));
         std::vector<uint32_t> sorted_idx = in_leaf_order;
         std::sort(sorted_idx.begin(), sorted_idx.end());
-        std::vector<rt::FlatTriangle> moved(in_leaf_order.size());
-        for (size_t k = 0; k < in_leaf_order.size(); ++k) moved[k] = out.triangles[in_leaf_order[k]];
-        for (size_t k = 0; k < in_leaf_order.size(); ++k) out.triangles[sorted_idx[k]] = moved[k];
+        bool exclusive = true;
+        for (size_t k = 0; k < sorted_idx.size(); ++k) {
+          if (sorted_idx[k] < tris_before) exclusive = false;
+          if (k > 0 && sorted_idx[k] == sorted_idx[k - 1]) exclusive = false;
+        }
+        if (exclusive) {
+          std::vector<rt::FlatTriangle> moved(in_leaf_order.size());
+          for (size_t k = 0; k < in_leaf_order.size(); ++k) moved[k] = out.triangles[in_leaf_order[k]];
+          for (size_t k = 0; k < in_leaf_order.size(); ++k) out.triangles[sorted_idx[k]] = moved[k];
+        } else {
+          const uint32_t base = (uint32_t)out.triangles.size();
+          for (size_t k = 0; k < in_leaf_order.size(); ++k) {
+            const rt::FlatTriangle copy = out.triangles[in_leaf_order[k]];
+            out.triangles.push_back(copy);
+            sorted_idx[k] = base + (uint32_t)k;
+          }
+        }
         size_t k = 0;
         for (size_t i = 0; i < refs.size(); ++i) {
           rt::PrimRef r = refs[order[i]];
-          if (rt::primref_type(r) == rt::PRIM_TRIANGLE) r = rt::make_primref(rt::PRIM_TRIANGLE, sorted_idx[k++]);
+          if (rt::primref_type(r) == rt::PRIM_TRIANGLE) {
+            r = rt::make_primref(rt::PRIM_TRIANGLE, sorted_idx[k++]);
+            if (exclusive && handles[order[i]] >= 0) prim_of[handles[order[i]]] = (int64_t)r;
+          }
           out.refs.push_back(r);
         }
       }
       out.max_stack = std::max(out.max_stack, depth);
       out.n_bvh++;
-      return push_entry(e);
+      return bvh_entry_of[h] = push_entry(e);
     }
     fail("unsupported object where geometry is expected (transform of a transform chain > 2, medium inside a wrapper, ...)");
     return -1;

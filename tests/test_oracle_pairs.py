@@ -146,3 +146,101 @@ def test_statistical_agreement_between_scene_seeds(rtsr, orc):
         a, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, 32, threads=8)
         means.append(a.mean() / 4)
     assert means[0] != means[1] and abs(means[0] - means[1]) < 0.1
+
+
+# ---- objects shared between containers (the reference holds every object as an Arc: one Triangle, or one BvhNode,
+# may sit in several lists / under several Translates) and degenerate boxes ---------------------------------------
+def _tri_fan(b, mat, n, z0=0.0, dx=0.0):
+    """n small non-coplanar triangles on a grid facing +z (slightly tilted so that no bounding box is flat)."""
+    tris = []
+    for k in range(n):
+        x, y = (k % 8) * 1.0 - 4.0 + dx, (k // 8) * 1.0 - 2.0
+        tris.append(b.triangle((x, y, z0 + 0.05 * (k % 3)), (x + 0.9, y, z0), (x, y + 0.9, z0 + 0.1), mat))
+    return tris
+
+
+def _shared_cam_cfg(rtsr):
+    cam = rtsr.Camera.new((0.0, 0.5, 14.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 50.0, 1.5, 0.0, 14.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.5, 96, 4, 8, 4, seed=3, background=(0.6, 0.7, 0.9))
+    return cam, cfg, rtsr.image_height(cfg)
+
+
+def shared_worlds(rtsr):
+    """(name, builder, world) for every sharing shape the flattener must keep apart."""
+    out = []
+    # (a) a triangle of a BVH is ALSO a plain entry under a Translate, listed after the BVH
+    b = rtsr.Builder(1)
+    m1, m2 = b.lambertian((0.8, 0.2, 0.2)), b.metal((0.7, 0.7, 0.7), 0.1)
+    tris = _tri_fan(b, m1, 24)
+    world = b.hittable_list([b.bvh_from_list(b.hittable_list(tris), 0.0, 1.0), b.translate((0.0, 5.0, 0.0), tris[6]),
+                             b.sphere((0.0, -1001.0, 0.0), 998.0, m2)])
+    out.append(("prim_shared_after_bvh", b, world))
+    # (a') the shared triangle is emitted BEFORE the BVH that also holds it
+    b = rtsr.Builder(1)
+    m1 = b.lambertian((0.2, 0.8, 0.2))
+    tris = _tri_fan(b, m1, 24)
+    world = b.hittable_list([b.translate((0.0, 5.0, 0.0), tris[3]), tris[17], b.bvh_from_list(b.hittable_list(tris), 0.0, 1.0)])
+    out.append(("prim_shared_before_bvh", b, world))
+    # (b) two BVHs over overlapping triangle sets
+    b = rtsr.Builder(1)
+    m1 = b.lambertian((0.2, 0.2, 0.8))
+    tris = _tri_fan(b, m1, 40)
+    world = b.hittable_list([b.bvh_from_list(b.hittable_list(tris[:30]), 0.0, 1.0),
+                             b.translate((0.3, 0.2, 1.0), b.bvh_from_list(b.hittable_list(tris[10:]), 0.0, 1.0))])
+    out.append(("overlapping_bvhs", b, world))
+    # (c) ONE BVH handle instanced under two transforms (and once plainly)
+    b = rtsr.Builder(1)
+    m1 = b.lambertian((0.8, 0.8, 0.2))
+    bvh = b.bvh_from_list(b.hittable_list(_tri_fan(b, m1, 24)), 0.0, 1.0)
+    world = b.hittable_list([bvh, b.translate((0.0, 3.2, 0.0), bvh), b.translate((0.0, -3.2, 0.0), b.rotate_y(20.0, bvh))])
+    out.append(("instanced_bvh", b, world))
+    # (d) the same triangle listed twice inside one BVH
+    b = rtsr.Builder(1)
+    m1 = b.lambertian((0.8, 0.2, 0.8))
+    tris = _tri_fan(b, m1, 16)
+    world = b.hittable_list([b.bvh_from_list(b.hittable_list(tris + [tris[5], tris[5]]), 0.0, 1.0)])
+    out.append(("duplicate_in_bvh", b, world))
+    return out
+
+
+@pytest.mark.parametrize("reference_bvh", [False, True], ids=["sah", "reference_rule"])
+def test_shared_objects_flatten_like_the_object_graph(rtsr, orc, reference_bvh):
+    cam, cfg, h = _shared_cam_cfg(rtsr)
+    for name, b, world in shared_worlds(rtsr):
+        a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8)
+        flat = b.flatten(world, reference_bvh=reference_bvh, bvh_seed=7)
+        a2, r2 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+        assert np.array_equal(a1, a2), "%s: %d pixels differ" % (name, int((np.abs(a1 - a2).max(axis=2) > 0).sum()))
+        assert np.array_equal(r1, r2), name
+        assert a1.std() > 0.01, name  # the geometry is in view
+
+
+def axis_aligned_world(rtsr, as_bvh):
+    """Triangles lying exactly in coordinate planes (zero-thickness boxes, hit.rs:164-177 pads nothing) among tilted
+    ones.  As a plain HittableList the reference hits every one of them; inside a BvhNode whether it does depends on
+    its random split axes (a flat union box is never entered, aabb.rs:58) -- this build always hits them."""
+    b = rtsr.Builder(1)
+    m = [b.lambertian(c) for c in ((0.8, 0.2, 0.2), (0.2, 0.8, 0.2), (0.2, 0.2, 0.8))]
+    tris = []
+    for k in range(12):
+        x = k * 0.8 - 4.8
+        tris.append(b.triangle((x, -1.0, 0.0), (x + 0.7, -1.0, 0.0), (x, 0.2, 0.0), m[k % 3]))          # in the plane z = 0
+        tris.append(b.triangle((x, 0.5, -1.0), (x + 0.7, 0.5, 0.3), (x, 0.5, 0.3), m[(k + 1) % 3]))      # in the plane y = 0.5
+        tris.append(b.triangle((x, 1.0, 0.0), (x + 0.7, 1.2, 0.4), (x + 0.1, 2.0, -0.3), m[(k + 2) % 3]))  # tilted
+    lst = b.hittable_list(tris)
+    world = b.hittable_list([b.bvh_from_list(lst, 0.0, 1.0)]) if as_bvh else lst
+    return b, world
+
+
+def test_axis_aligned_triangles(rtsr, orc):
+    cam = rtsr.Camera.new((0.5, 3.0, 9.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), 55.0, 1.5, 0.0, 9.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.5, 96, 4, 8, 4, seed=3, background=(0.6, 0.7, 0.9))
+    h = rtsr.image_height(cfg)
+    b0, list_world = axis_aligned_world(rtsr, as_bvh=False)
+    expect, expect8 = orc.o1_render(b0.graph_ptr(), list_world, cam, cfg, h, threads=8)  # literal list scan: no boxes involved
+    b1, bvh_world = axis_aligned_world(rtsr, as_bvh=True)
+    for kw in ({}, {"max_leaf": 1}, {"max_leaf": 4}, {"reference_bvh": True, "bvh_seed": 1}, {"reference_bvh": True, "bvh_seed": 2}):
+        flat = b1.flatten(bvh_world, **kw)
+        a2, r2 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+        assert np.array_equal(expect, a2), "%r: %d pixels differ" % (kw, int((np.abs(expect - a2).max(axis=2) > 0).sum()))
+        assert np.array_equal(expect8, r2)
