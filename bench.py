@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s (pixels x spp) of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c1|head|c5] [--spp S]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c1|head|c3|c4|c5] [--spp S]
 
 A "step" is one full render of the workload: trace kernel(s) + ordered sample reduction + tone map,
 scene already resident in HBM.  At N=1 the workload is BASELINE.json configs[1] ("c2": Book-1 final
@@ -10,21 +10,39 @@ process per GPU, launched by torch.distributed.run) and the tone-mapped shards a
 with one RCCL gather per step: total work is fixed, so scaling is "strong".
 
 One JSON line is printed by rank 0.  Besides the driver's contract it carries
-  roofline      algorithmic bytes (SURVEY.md 8d model, counts from an instrumented run of the same
-                pixels/seeds) / mean trace-kernel duration measured with HIP events on the launch stream
+
+  roofline      bound = "valu": the trace kernels are bound by vector-ALU ISSUE (the Book-1 scene lives in LDS; HBM
+                sees 2 % of its peak).  Everything in it is measured in THIS run (rank 0, N = 1) by rocprofv3 --pmc
+                passes over a child process that renders the same workload:
+                  frac = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel clocks)
+                = clocks in which a SIMD's VALU is occupied by an instruction / clocks available, kernel clocks =
+                GRBM_GUI_ACTIVE / 8 XCDs of the same pass.  (ACTIVE_INST_VALU alone double counts quad-cycles that two
+                2-clock instructions share -- it exceeded the available time in round 1; VALU2 is exactly that overlap,
+                see PMC_PASSES.)  `useful` = frac x lane utilisation.  As a cross-check the same fraction is priced
+                from per-class instruction counts (SQ_INSTS_VALU_*) x per-opcode issue costs measured by lib/issue_calib
+                in this run (tools/gen_issue_calib.py).  HBM (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and the
+                SURVEY 8(d) algorithmic-bytes figure ride along as secondary fields.
   cpu_baseline  the CPU oracle O1 (literal restatement of the reference's path, "port") timed on this
                 box's host cores on a bounded sample of the same workload
+  other_workloads  (N = 1) the other BASELINE configs on the HIP path, a few steps each: Book-1 as HEAD builds it,
+                C3 (Book-2, reduced spp), C4 (871 200-triangle mesh room, full), C5's frame on one GPU (reduced spp)
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+LIB_DIR = os.path.join(ROOT, "ray-tracing-series-rust_amd", "lib")
 
 WORKLOADS = {
     # name: (scene id, image width, image aspect, spp, depth, description)
@@ -38,6 +56,23 @@ WORKLOADS = {
 # fixed f64 struct sizes of the algorithmic-bytes model
 S_NODE, S_SPHERE, S_MSPHERE, S_RECT, S_TRI, S_MAT, S_TEXEL, S_PERLIN, S_OUT = 64, 48, 80, 48, 112, 48, 4, 8 * 24, 24
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_XCD = 8              # MI355X_MICROARCH.md chip-level parameters
+
+# rocprofv3 counter passes (<= 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE cannot share a pass)
+PMC_PASSES = [
+    # pass 0: VALU-active time.  SQ_ACTIVE_INST_VALU = quad-cycles (4 clocks) an instruction occupies the SIMD's VALU, counted
+    # per instruction; SQ_ACTIVE_INST_VALU2 = quad-cycles in which TWO instructions are active at once (two 2-clock
+    # instructions of different waves share a quad).  Their difference is the union: quad-cycles the VALU is busy.
+    # Checked on the per-opcode calibration kernels (profiles/r02/classify_c.csv): 4 x (VALU - VALU2) per instruction
+    # reproduces each opcode's measured issue clocks (2 / 4 / 8 / 16) within 2 %.
+    ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES",
+     "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+     "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT", "GRBM_GUI_ACTIVE", "WRITE_SIZE"],
+    ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+     "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],
+]
+VALU_CLASSES = ["ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT32", "INT64", "CVT"]
 
 
 def algorithmic_bytes(c):
@@ -62,6 +97,185 @@ def usable_cores():
     return cores
 
 
+# ------------------------------------------------------------------------------------------- workload set-up
+def build_workload(rtsr, name, spp_override=0, max_leaf=0, sah_bins=0):
+    sid, width, aspect, spp, depth, desc = WORKLOADS[name]
+    if spp_override > 0:
+        spp = spp_override
+    b = rtsr.Builder(1)  # scene seed 1 on every rank -> identical scene
+    world, cam, bg = b.get_world_cam(sid, camera_aspect=aspect if sid in (100, 13) else 0.0)
+    cfg = rtsr.Config.new(aspect, width, spp, depth, 10, seed=1, background=bg)
+    t0 = time.perf_counter()
+    flat = b.flatten(world, max_leaf=max_leaf, sah_bins=sah_bins)
+    t_flat = time.perf_counter() - t0
+    return {"builder": b, "world": world, "cam": cam, "cfg": cfg, "flat": flat, "width": width, "height": rtsr.image_height(cfg),
+            "spp": spp, "depth": depth, "desc": desc, "flatten_s": t_flat, "bg": bg}
+
+
+# ------------------------------------------------------------------------------------------- PMC child
+def pmc_child(args):
+    """Runs under `rocprofv3 --pmc ...`: renders the workload a few times through the C ABI.  No torch here."""
+    rtsr = importlib.import_module("ray-tracing-series-rust_amd")
+    w = build_workload(rtsr, args.workload, args.spp, args.max_leaf, args.sah_bins)
+    scene = w["flat"].upload()
+    for _ in range(max(1, args.steps)):
+        scene.render_device(w["cam"], w["cfg"], want_stats=True)  # want_stats synchronises
+    return 0
+
+
+def run_issue_calib(waves_per_simd=4):
+    exe = os.path.join(LIB_DIR, "issue_calib")
+    if not os.path.exists(exe):
+        return None, "lib/issue_calib missing (python ray-tracing-series-rust_amd/build.py builds it)"
+    try:
+        out = subprocess.run([exe, str(waves_per_simd), "100", "3"], capture_output=True, text=True, timeout=180)
+        if out.returncode != 0:
+            return None, "issue_calib failed: " + out.stderr[-200:]
+        return json.loads(out.stdout), None
+    except Exception as e:  # noqa: BLE001
+        return None, "issue_calib: %r" % (e,)
+
+
+def run_pmc_passes(args, passes, keep_dir=None):
+    """One rocprofv3 child per counter group; returns ({counter: mean per trace-kernel dispatch}, info)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    info = {"passes": [], "errors": []}
+    if not os.path.exists(exe):
+        info["errors"].append("rocprofv3 not found")
+        return {}, info
+    merged, kernel_name, durations = {}, None, []
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for n, counters in enumerate(passes):
+        out_dir = tempfile.mkdtemp(prefix="rtx_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out_dir, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload, "--steps", "3"]
+        if args.spp > 0:
+            cmd += ["--spp", str(args.spp)]
+        if args.max_leaf:
+            cmd += ["--max-leaf", str(args.max_leaf)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                info["errors"].append("pass %d rc=%d: %s" % (n, r.returncode, (r.stderr or r.stdout)[-300:]))
+                continue
+            per_counter = {}
+            for row in csv.DictReader(open(files[0])):
+                if "k_trace" not in row["Kernel_Name"]:
+                    continue
+                kernel_name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                per_counter.setdefault(row["Counter_Name"], {})[row["Dispatch_Id"]] = (
+                    float(row["Counter_Value"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+            for cname, disp in per_counter.items():
+                vals = [v for v, _ in disp.values()]
+                merged.setdefault(cname, []).append(sum(vals) / len(vals))
+                if cname == "GRBM_GUI_ACTIVE" or cname == counters[0]:
+                    durations.append(sum(ms for _, ms in disp.values()) / len(disp))
+            info["passes"].append({"counters": counters, "seconds": round(time.perf_counter() - t0, 1),
+                                   "dispatches": len(next(iter(per_counter.values()))) if per_counter else 0})
+            if keep_dir:
+                os.makedirs(keep_dir, exist_ok=True)
+                shutil.copy(files[0], os.path.join(keep_dir, "pmc_pass%d.csv" % n))
+        except Exception as e:  # noqa: BLE001
+            info["errors"].append("pass %d: %r" % (n, e))
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    out = {k: sum(v) / len(v) for k, v in merged.items()}
+    info["kernel"] = kernel_name
+    info["pmc_kernel_ms"] = round(sum(durations) / len(durations), 3) if durations else None
+    return out, info
+
+
+def valu_active_fraction(pmc, pmc_info, n_cu):
+    """The headline fraction: quad-cycles the SIMDs' VALUs are busy / quad-cycles available, straight from the counters."""
+    need = ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE"]
+    if any(c not in pmc for c in need):
+        return None
+    kernel_clocks = pmc["GRBM_GUI_ACTIVE"] / N_XCD
+    simds = 4.0 * n_cu
+    busy_clocks = 4.0 * (pmc["SQ_ACTIVE_INST_VALU"] - pmc["SQ_ACTIVE_INST_VALU2"])
+    t_s = (pmc_info.get("pmc_kernel_ms") or 0.0) * 1e-3
+    res = {"frac": round(busy_clocks / (simds * kernel_clocks), 4), "busy_clocks_per_launch": round(busy_clocks),
+           "kernel_clocks": round(kernel_clocks), "simds": int(simds),
+           "clock_ghz": round(kernel_clocks / t_s / 1e9, 3) if t_s > 0 else None,
+           "achieved": round(busy_clocks / t_s / 1e9, 1) if t_s > 0 else None,
+           "peak": round(simds * kernel_clocks / t_s / 1e9, 1) if t_s > 0 else None}
+    if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+        res["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        res["useful"] = round(res["frac"] * res["lane_utilisation"], 4)
+    if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES"):
+        res["kernel_clocks_from_wave_cycles"] = round(4.0 * pmc["SQ_WAVE_CYCLES"] / pmc["SQ_WAVES"])
+        res["wait_any_per_wave_cycle"] = round(pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"], 4)
+        res["wait_inst_any_per_wave_cycle"] = round(pmc.get("SQ_WAIT_INST_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"], 4)
+    return res
+
+
+def valu_roofline(pmc, pmc_info, calib, n_cu):
+    """Cross-check of valu_active_fraction from instruction counts: sum_class(count x cost) / (SIMDs x kernel clocks),
+    cost of a class = the kernel's static opcode mix inside that class priced per opcode (an ESTIMATE: the dynamic mix
+    inside a hardware class is not observable; frac_lo / frac_hi bracket it)."""
+    mix_path = os.path.join(LIB_DIR, "kernel_mix.json")
+    cls_path = os.path.join(ROOT, "profiles", "opcode_classes.json")
+    need = ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"] + ["SQ_INSTS_VALU_" + c for c in VALU_CLASSES]
+    missing = [c for c in need if c not in pmc]
+    if missing or calib is None or not os.path.exists(mix_path) or not os.path.exists(cls_path):
+        return None, "missing: %s%s%s%s" % (",".join(missing), " calib" if calib is None else "",
+                                            "" if os.path.exists(mix_path) else " kernel_mix.json", "" if os.path.exists(cls_path) else " opcode_classes.json")
+    kernels = json.load(open(mix_path))["kernels"]
+    kname = pmc_info.get("kernel")
+    static = kernels.get(kname, {}).get("valu")
+    if not static:
+        return None, "kernel %r not in kernel_mix.json" % (kname,)
+    op_class = json.load(open(cls_path))["class_of"]
+    clk = calib["clocks_per_wave_inst"]
+    # nearest known opcode for the few the generator cannot benchmark (sdwa forms, v_cmpx): same mnemonic stem
+    def clocks_of(op):
+        if op in clk:
+            return clk[op]
+        stem = op.replace("_sdwa", "_e32").replace("_dpp", "_e32").replace("v_cmpx_", "v_cmp_")
+        for cand in (stem, stem.replace("_e32", "_e64"), stem.replace("_e64", "_e32"), stem.replace("_e32", "")):
+            if cand in clk:
+                return clk[cand]
+        return None
+    per_class = {}
+    for op, n in static.items():
+        c = clocks_of(op)
+        if c is None:
+            continue
+        cls = op_class.get(op) or op_class.get(op.replace("_sdwa", "_e32").replace("v_cmpx_", "v_cmp_")) or "OTHER"
+        d = per_class.setdefault(cls, {"n": 0, "clk": 0.0, "lo": 1e9, "hi": 0.0})
+        d["n"] += n; d["clk"] += n * c; d["lo"] = min(d["lo"], c); d["hi"] = max(d["hi"], c)
+    counts = {c: pmc["SQ_INSTS_VALU_" + c] for c in VALU_CLASSES}
+    counts["OTHER"] = max(0.0, pmc["SQ_INSTS_VALU"] - sum(counts.values()))
+    busy = busy_lo = busy_hi = 0.0
+    classes = {}
+    for cls, n_dyn in counts.items():
+        d = per_class.get(cls)
+        if d is None or d["n"] == 0:  # a class the static mix does not hold: price it like the cheapest f32 instruction
+            mean = lo = hi = min(clk.values())
+        else:
+            mean, lo, hi = d["clk"] / d["n"], d["lo"], d["hi"]
+        busy += n_dyn * mean; busy_lo += n_dyn * lo; busy_hi += n_dyn * hi
+        classes[cls] = {"insts": round(n_dyn), "clocks_per_inst": round(mean, 2)}
+    kernel_clocks = pmc["GRBM_GUI_ACTIVE"] / N_XCD
+    simds = 4.0 * n_cu
+    t_s = (pmc_info.get("pmc_kernel_ms") or 0.0) * 1e-3
+    res = {"frac": round(busy / (simds * kernel_clocks), 4), "frac_lo": round(busy_lo / (simds * kernel_clocks), 4),
+           "frac_hi": round(busy_hi / (simds * kernel_clocks), 4), "issue_clocks_per_launch": round(busy),
+           "kernel_clocks": round(kernel_clocks), "simds": int(simds), "classes": classes,
+           "clock_ghz": round(kernel_clocks / t_s / 1e9, 3) if t_s > 0 else None,
+           "achieved": round(busy / t_s / 1e9, 1) if t_s > 0 else None, "peak": round(simds * kernel_clocks / t_s / 1e9, 1) if t_s > 0 else None}
+    if "SQ_THREAD_CYCLES_VALU" in pmc and pmc.get("SQ_ACTIVE_INST_VALU"):
+        res["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        res["useful"] = round(res["frac"] * res["lane_utilisation"], 4)
+    if "SQ_BUSY_CYCLES" in pmc:
+        res["kernel_clocks_sq_busy_over_32se"] = round(pmc["SQ_BUSY_CYCLES"] / 32.0)
+    return res, None
+
+
+# ------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,13 +288,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal on a box with fewer GPUs than ranks (shards gathered through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline then reports no VALU fraction)")
+    ap.add_argument("--keep-pmc", default="", help="directory to keep the raw counter CSVs in")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="SAH bin count override (0 = library default)")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    if args.pmc_child:
+        return pmc_child(args)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,6 +305,20 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world_size, args.gpus))
+
+    # ---- measurements that run in child processes come first: this process has not touched the GPU yet
+    calib = calib_err = None
+    pmc, pmc_info = {}, {"errors": ["skipped"]}
+    if rank == 0 and world_size == 1 and not args.no_pmc:
+        calib, calib_err = run_issue_calib(4)
+        pmc, pmc_info = run_pmc_passes(args, PMC_PASSES, keep_dir=args.keep_pmc or None)
+        if calib is not None and args.keep_pmc:
+            json.dump(calib, open(os.path.join(args.keep_pmc, "issue_calib.json"), "w"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU render path")
     n_dev = torch.cuda.device_count()
@@ -103,17 +333,11 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
 
     rtsr = importlib.import_module("ray-tracing-series-rust_amd")
-    sid, width, aspect, spp, depth, desc = WORKLOADS[args.workload]
-    if args.spp > 0:
-        spp = args.spp
-    b = rtsr.Builder(1)  # scene seed 1 on every rank -> identical scene
-    world, cam, bg = b.get_world_cam(sid, camera_aspect=aspect if sid in (100, 13) else 0.0)
-    cfg = rtsr.Config.new(aspect, width, spp, depth, 10, seed=1, background=bg)
-    height = rtsr.image_height(cfg)
-    t_flat = time.perf_counter()
-    flat = b.flatten(world, max_leaf=args.max_leaf, sah_bins=args.sah_bins)
-    t_flat = time.perf_counter() - t_flat
+    w = build_workload(rtsr, args.workload, args.spp, args.max_leaf, args.sah_bins)
+    b, world, cam, cfg, flat = w["builder"], w["world"], w["cam"], w["cfg"], w["flat"]
+    width, height, spp, depth, desc = w["width"], w["height"], w["spp"], w["depth"], w["desc"]
     scene = flat.upload()
+    n_cu = torch.cuda.get_device_properties(device_index).multi_processor_count
 
     shard = (rank, world_size, 1)  # rows j with j % N == rank
     my_rows = rtsr.shard_rows(cfg, shard)
@@ -175,7 +399,42 @@ def main():
     if rank == 0:
         launches = sum(n for _, n in trace_ms)
         mean_trace_ms = sum(ms for ms, _ in trace_ms) / max(1, launches)
-        roofline = None
+        kernel_name = rtsr.trace_kernel_name(kernel_used[-1]) if kernel_used else "?"
+        roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": None, "unit": "G issue-clk/s (VALU issue clocks over all SIMDs)",
+                    "frac": None, "traffic": None, "kernel_ms": round(mean_trace_ms, 3)}
+        # -- VALU issue roofline from this run's counter passes + calibration
+        if pmc:
+            va = valu_active_fraction(pmc, pmc_info, n_cu)
+            if va is not None:
+                roofline.update(va)
+                roofline["kernel"] = pmc_info.get("kernel") or kernel_name
+                roofline["pmc_kernel_ms"] = pmc_info.get("pmc_kernel_ms")
+                roofline["formula"] = "frac = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x GRBM_GUI_ACTIVE / 8)"
+                roofline["source"] = ("measured in this run: %d rocprofv3 --pmc passes over a child process rendering the same workload" %
+                                      len(pmc_info.get("passes", [])))
+            vr, err = valu_roofline(pmc, pmc_info, calib, n_cu)
+            if vr is not None:
+                # cross-check from instruction counts: every hardware class priced at its cheapest / dearest opcode of the
+                # shipped kernel (issue costs measured by lib/issue_calib in this run) must bracket the measured fraction
+                roofline["priced_from_instruction_counts"] = {"frac_lo": vr["frac_lo"], "frac_hi": vr["frac_hi"], "classes": vr["classes"],
+                                                              "note": "dynamic SQ_INSTS_VALU_* class counts x per-opcode issue clocks; the mix inside a class is not observable, hence a bracket"}
+            elif va is None:
+                roofline["valu_error"] = err
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KB) under-reports wide reads 2x on gfx950; WRITE_SIZE (KB) is exact
+                hbm_bytes = pmc["FETCH_SIZE"] * 1024.0 * 2.0 + pmc["WRITE_SIZE"] * 1024.0
+                roofline["traffic"] = round(hbm_bytes)
+                t_s = (pmc_info.get("pmc_kernel_ms") or mean_trace_ms) * 1e-3
+                roofline["hbm"] = {"achieved": round(hbm_bytes / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(hbm_bytes / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+            if pmc.get("SQ_ACTIVE_INST_LDS"):
+                roofline["lds"] = {"bank_conflict_per_active_cycle": round(pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / pmc["SQ_ACTIVE_INST_LDS"], 3),
+                                   "insts_per_launch": round(pmc.get("SQ_INSTS_LDS", 0.0))}
+        if pmc_info.get("errors") and pmc_info["errors"] != ["skipped"]:
+            roofline["pmc_errors"] = pmc_info["errors"][:3]
+        if calib_err:
+            roofline["calib_error"] = calib_err
+        # -- SURVEY 8(d) algorithmic bytes (a model figure: the scene is on chip, so it exceeds what HBM could deliver)
         if not args.no_count:
             count_spp = min(spp, args.count_spp)
             ccfg = rtsr.RtxConfig.from_buffer_copy(cfg)
@@ -186,33 +445,41 @@ def main():
             bytes_per_sample = algorithmic_bytes(counts) / float(counts["samples"])
             samples_per_launch = float(my_rows) * width * spp / max(1, launches // max(1, args.steps))
             achieved = bytes_per_sample * samples_per_launch / (mean_trace_ms * 1e-3) / 1e9
-            pmc = None
-            valu_issue = None
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_path):
+            roofline["algorithmic"] = {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": round(achieved, 1), "unit": "GB/s",
+                                       "over_hbm_peak": round(achieved / HBM_PEAK_GBS, 3),
+                                       "note": "SURVEY 8(d) model (every touch as if from memory); > 1 of HBM peak because the scene is LDS/L2 resident",
+                                       "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),
+                                       "box_tests_per_ray": round(counts["box_tests"] / float(max(1, counts["rays"])), 2),
+                                       "counted_on": "%d spp of the same pixels and seeds" % count_spp}
+        # -- the other BASELINE configs on the HIP path (short runs; C2 stays the headline)
+        extras = None
+        if world_size == 1 and not args.no_extras and args.workload == "c2" and args.spp == 0:
+            extras = {}
+            del scene  # free C2's sample buffer first
+            torch.cuda.empty_cache()
+            for name, x_spp, x_steps in (("head", 0, 3), ("c3", 256, 2), ("c4", 0, 2), ("c5", 120, 1)):
                 try:
-                    rec = json.load(open(pmc_path))
-                    if rec.get("workload") == args.workload and rec.get("spp") == spp and world_size == 1:
-                        pmc = rec.get("hbm_bytes_per_launch")
-                        sq = rec.get("sq") or {}
-                        if sq.get("SQ_INSTS_VALU") and sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAVES"):
-                            # what actually bounds this kernel (the scene is on chip): VALU issue.  A SIMD issues one
-                            # wave64 VALU instruction per 4 clocks; SQ cycle counters tick once per 4 clocks.
-                            simds = 4.0 * torch.cuda.get_device_properties(0).multi_processor_count
-                            quad_cycles = sq["SQ_WAVE_CYCLES"] / sq["SQ_WAVES"]  # kernel duration, every wave lives through it
-                            valu_issue = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"],
-                                          "frac_of_issue_peak": round(sq["SQ_ACTIVE_INST_VALU"] / (simds * quad_cycles), 3),
-                                          "lane_utilisation": round(rec.get("lane_utilisation", 0.0), 3),
-                                          "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_* pass of this workload)"}
-                except Exception:
-                    pmc = None
-            roofline = {"bound": "hbm", "kernel": rtsr.trace_kernel_name(kernel_used[-1]) if kernel_used else "?", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc, "valu_issue": valu_issue,
-                        "bytes_per_sample": round(bytes_per_sample, 1), "kernel_ms": round(mean_trace_ms, 3),
-                        "rays_per_sample": round(counts["rays"] / float(counts["samples"]), 3),
-                        "box_tests_per_ray": round(counts["box_tests"] / float(max(1, counts["rays"])), 2),
-                        "counted_on": "%d spp of the same pixels and seeds" % count_spp,
-                        "per_ray": {k: round(v / float(max(1, counts["rays"])), 3) for k, v in counts.items() if k not in ("rays", "samples") and v}}
+                    xw = build_workload(rtsr, name, x_spp)
+                    t_up = time.perf_counter()
+                    xs = xw["flat"].upload()
+                    t_up = time.perf_counter() - t_up
+                    xs.render_device(xw["cam"], xw["cfg"], stream=stream, want_stats=True)  # warm-up
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    ms, kern = 0.0, None
+                    for _ in range(x_steps):
+                        st = xs.render_device(xw["cam"], xw["cfg"], stream=stream, want_stats=True)
+                        ms += st.trace_ms
+                        kern = st.trace_kernel
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t1) / x_steps
+                    extras[name] = {"workload": xw["desc"] + ("" if x_spp == 0 else " -- run at %d spp" % x_spp),
+                                    "value": round(xw["width"] * xw["height"] * xw["spp"] / dt / 1e6, 1), "unit": "Msamples/s",
+                                    "ms_per_step": round(dt * 1e3, 2), "trace_ms": round(ms / x_steps, 2), "kernel": rtsr.trace_kernel_name(kern),
+                                    "flatten_s": round(xw["flatten_s"], 2), "upload_s": round(t_up, 2)}
+                    del xs
+                except Exception as e:  # noqa: BLE001
+                    extras[name] = {"error": repr(e)[:200]}
         cpu = None
         if not args.no_cpu_baseline and world_size == 1:  # a reported baseline: rank 0 at N=1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -240,22 +507,27 @@ def main():
             dt10 = time.perf_counter() - t0
             cpu["ten_threads"] = {"value": round(width * height * spp10 / dt10 / 1e6, 4), "cores": 10,
                                   "sample": "%d spp, %.1f s" % (spp10, dt10)}
+            cpu["gpu_over_cpu"] = {"vs_all_cores": round(value / cpu["value"], 1), "vs_ten_threads": round(value / cpu["ten_threads"]["value"], 1),
+                                   "vs_readme_ten_threads": round(value / 1.4559, 1)}
         out = {
             "metric": "Msamples/s (pixels x spp) on Book-1 final scene" if args.workload in ("c1", "c2", "c5") else "Msamples/s (pixels x spp)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": round(value / 1.4559, 1), "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "width": width, "height": height, "spp": spp, "max_depth": depth,
-                       "scene_seed": 1, "render_seed": 1, "flatten_s": round(t_flat, 3), "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
+                       "scene_seed": 1, "render_seed": 1, "flatten_s": round(w["flatten_s"], 3), "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
                        if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_cpu_published": {"value": 1.4559, "unit": "Msamples/s", "source": "README.md:23, 10 threads, CPU unstated"},
         }
+        if extras is not None:
+            out["other_workloads"] = extras
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -64,6 +64,33 @@ def build_library(force=False, verbose=True):
     return LIB_PATH
 
 
+def build_roofline_tools(force=False, verbose=True):
+    """lib/kernel_mix.json (static VALU opcode mix of every trace kernel) and lib/issue_calib (issue-cost micro-benchmark
+    of exactly those opcodes), both derived from the device assembly of the sources the library was built from.
+    bench.py's roofline uses them (tools/kernel_mix.py, tools/gen_issue_calib.py)."""
+    mix = os.path.join(LIB_DIR, "kernel_mix.json")
+    calib = os.path.join(LIB_DIR, "issue_calib")
+    tools = os.path.join(REPO_DIR, "tools")
+    deps = [os.path.join(PKG_DIR, "csrc"), tools]
+    if not force and not needs_build(mix, deps) and not needs_build(calib, deps):
+        return mix
+    gen_dir = os.path.join(tools, "_gen")
+    os.makedirs(gen_dir, exist_ok=True)
+    asm = os.path.join(gen_dir, "render_gfx950.s")
+    flags = [f for f in HIP_FLAGS if f != "-fPIC"]
+    cmds = [
+        [_hipcc()] + flags + ["-S", "--cuda-device-only", os.path.join(PKG_DIR, "csrc/hip/render.hip"), "-o", asm],
+        [sys.executable, os.path.join(tools, "kernel_mix.py"), asm, mix],
+        [sys.executable, os.path.join(tools, "gen_issue_calib.py"), asm, os.path.join(gen_dir, "issue_calib_auto.hip")],
+        [_hipcc(), "--offload-arch=gfx950", "-O1", "-std=c++17", os.path.join(gen_dir, "issue_calib_auto.hip"), "-o", calib],
+    ]
+    for cmd in cmds:
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=PKG_DIR)
+    return mix
+
+
 def build_app(force=False, verbose=True):
     """apps/rtx_render: the stand-in for the reference's src/main.rs, linked against the library."""
     src = os.path.join(PKG_DIR, "apps", "rtx_render.cpp")
@@ -83,3 +110,4 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     build_library(force=force)
     build_app(force=force)
+    build_roofline_tools(force=force)

@@ -53,7 +53,7 @@ def test_reference_images_black_top_rows(rtsr, orc, tmp_path, name, sid, width, 
     assert n_black == black_top
     # and the rendered part equals the oracle's (spot rows: the frame is a megapixel)
     for j in (0, rendered // 2, rendered - 1):
-        ref, ref8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=(j, h, 1), threads=8)
+        ref, ref8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=(j, h, 1), threads=threads)  # the oracle reads the band count from `threads` too
         assert np.array_equal(screen.accum[j], ref[0]) and np.array_equal(screen.rgb8[j], ref8[0]), j
         assert np.array_equal(px[h - 1 - j], ref8[0].astype(np.int64))
 
