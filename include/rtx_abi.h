@@ -39,6 +39,7 @@ typedef int32_t rtx_status;
 #define RTX_EHIP 3         /* a HIP runtime call failed (includes "no GPU") */
 #define RTX_EUNSUPPORTED 4 /* scene shape outside what the kernels implement */
 #define RTX_EIO 5          /* file could not be read/written (reference: expect()/unwrap() panics) */
+#define RTX_ENCCL 6        /* RCCL could not be loaded, or a collective failed */
 
 typedef int32_t rtx_handle; /* >= 0 valid, < 0 error */
 
@@ -216,6 +217,29 @@ rtx_status rtx_render_device(const rtx_scene* s, const RtxCamera* cam, const Rtx
 /* Instrumented render of the same shard: fills the work counters of RtxRenderStats (blocking). */
 rtx_status rtx_render_count(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
                             const RtxShard* shard, RtxRenderStats* stats);
+
+/* ---- one process, several GPUs: replaces the band threads + collect loop of render_scene (world.rs:1198-1244) ---- */
+/* The frame is cut into n_shards row-interleaved shards (RtxShard with shard_count = n_shards); shard r is rendered
+ * by device device_ids[r] (NULL: device r) into that device's HBM, then ONE RCCL gather (ncclGather over xGMI, a
+ * communicator from ncclCommInitAll) brings the shards to the first device, where they are put in row order and
+ * copied to the host buffers of `out`.  The scene is uploaded to every device once, at creation, and stays resident
+ * across renders.  device_ids must be all distinct -- or all equal, which renders the shards one after another on
+ * that one GPU without the collective (a rehearsal of the sharding on a single-GPU box).  The frame is byte-identical
+ * to rtx_render's for every shard count.  n_shards = 1 with one device goes through RCCL as well. */
+typedef struct rtx_multi rtx_multi;
+typedef struct RtxMultiStats {
+  double render_ms_max;   /* slowest device, first launch to end of tone map (HIP events) */
+  double total_ms;        /* host wall time of the call: launches + gather + reorder + copy to the host */
+  uint64_t gathered_bytes;
+  int32_t n_shards, n_devices, used_rccl, reserved;
+} RtxMultiStats;
+rtx_status rtx_multi_create(const rtx_flat* f, int32_t n_shards, const int32_t* device_ids, int32_t block_rows,
+                            rtx_multi** out);
+void rtx_multi_destroy(rtx_multi* m); /* NULL-safe */
+/* Blocking.  out->rgb8 and / or out->accum_rgb: host buffers of h*w*3 elements (row 0 = bottom row). stats may be NULL. */
+rtx_status rtx_multi_render(rtx_multi* m, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out, RtxMultiStats* stats);
+/* Convenience: create on devices 0..n_gpus-1 (block_rows 1), render once, destroy. */
+rtx_status rtx_render_multi(const rtx_flat* f, const RtxCamera* cam, const RtxConfig* cfg, int32_t n_gpus, RtxFrame* out);
 
 /* ---- image output: Screen::write_to_ppm_file  screen.rs:40-59 ------------------------------ */
 /* rgb8 in the row order above (row 0 = bottom); writes "P3\n{w} {h}\n255\n" then one "r g b" line

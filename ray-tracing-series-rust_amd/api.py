@@ -18,8 +18,8 @@ import numpy as np
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_PKG_DIR, "lib", "librtx_hip.so")
 
-RTX_OK, RTX_EINVAL, RTX_ENOMEM, RTX_EHIP, RTX_EUNSUPPORTED, RTX_EIO = 0, 1, 2, 3, 4, 5
-_STATUS_NAMES = {0: "RTX_OK", 1: "RTX_EINVAL", 2: "RTX_ENOMEM", 3: "RTX_EHIP", 4: "RTX_EUNSUPPORTED", 5: "RTX_EIO"}
+RTX_OK, RTX_EINVAL, RTX_ENOMEM, RTX_EHIP, RTX_EUNSUPPORTED, RTX_EIO, RTX_ENCCL = 0, 1, 2, 3, 4, 5, 6
+_STATUS_NAMES = {0: "RTX_OK", 1: "RTX_EINVAL", 2: "RTX_ENOMEM", 3: "RTX_EHIP", 4: "RTX_EUNSUPPORTED", 5: "RTX_EIO", 6: "RTX_ENCCL"}
 
 SCENE_CHECKERED_SPHERES, SCENE_TWO_PERLIN, SCENE_EARTH, SCENE_SIMPLE_LIGHT = 0, 1, 2, 3
 SCENE_CORNELL_BOX, SCENE_CORNELL_SMOKE, SCENE_BOOK2_FINAL, SCENE_MOVING_TEST = 4, 5, 6, 7
@@ -74,6 +74,11 @@ class RtxRenderStats(C.Structure):
                 ("trace_kernel", C.c_int32), ("reserved", C.c_int32)]
 
 
+class RtxMultiStats(C.Structure):
+    _fields_ = [("render_ms_max", C.c_double), ("total_ms", C.c_double), ("gathered_bytes", C.c_uint64),
+                ("n_shards", C.c_int32), ("n_devices", C.c_int32), ("used_rccl", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RtxShard(C.Structure):
     _fields_ = [("shard_index", C.c_int32), ("shard_count", C.c_int32), ("block_rows", C.c_int32), ("reserved", C.c_int32)]
 
@@ -119,6 +124,10 @@ ABI = {
     "rtx_config_new": (C.c_int32, [C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RtxConfig)]),
     "rtx_image_height": (C.c_int32, [C.POINTER(RtxConfig)]),
     "rtx_flat_top_level_kind": (C.c_int32, [_VP, C.c_int32]),
+    "rtx_multi_create": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_VP)]),
+    "rtx_multi_destroy": (None, [_VP]),
+    "rtx_multi_render": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.POINTER(RtxFrame), C.POINTER(RtxMultiStats)]),
+    "rtx_render_multi": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.c_int32, C.POINTER(RtxFrame)]),
     "rtx_get_world_cam": (C.c_int32, [_VP, C.c_int32, C.POINTER(RtxSceneOptions), C.POINTER(_H), C.POINTER(RtxCamera), _D3]),
     "rtx_flatten": (C.c_int32, [_VP, _H, C.POINTER(RtxBuildOptions), C.POINTER(_VP)]),
     "rtx_flat_destroy": (None, [_VP]),
@@ -415,6 +424,44 @@ class Scene:
         stats = RtxRenderStats()
         _check(lib.rtx_render_count(self._p, C.byref(cam), C.byref(cfg), C.byref(sh) if sh else None, C.byref(stats)))
         return stats
+
+
+class MultiScene:
+    """The scene resident on several GPUs of this process (rtx_multi): row-interleaved shards, one RCCL gather."""
+
+    def __init__(self, flat, n_shards, device_ids=None, block_rows=1):
+        ids = (C.c_int32 * n_shards)(*device_ids) if device_ids is not None else None
+        p = _VP()
+        _check(lib.rtx_multi_create(flat.ptr, n_shards, ids, block_rows, C.byref(p)))
+        self._p = p
+
+    def __del__(self):
+        p, self._p = getattr(self, "_p", None), None
+        if p:
+            lib.rtx_multi_destroy(p)
+
+    def render(self, cam, cfg, want_accum=True):
+        w, h = cfg.image_width, image_height(cfg)
+        accum = np.zeros((h, w, 3), dtype=np.float64) if want_accum else None
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        frame = RtxFrame(accum.ctypes.data_as(C.POINTER(C.c_double)) if want_accum else None,
+                         rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
+        stats = RtxMultiStats()
+        _check(lib.rtx_multi_render(self._p, C.byref(cam), C.byref(cfg), C.byref(frame), C.byref(stats)))
+        screen = Screen(w, h, rgb8, accum)
+        screen.stats = stats
+        return screen
+
+
+def render_multi(flat, cam, cfg, n_gpus, want_accum=True):
+    """rtx_render_multi: create on devices 0..n_gpus-1, render once, destroy."""
+    w, h = cfg.image_width, image_height(cfg)
+    accum = np.zeros((h, w, 3), dtype=np.float64) if want_accum else None
+    rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+    frame = RtxFrame(accum.ctypes.data_as(C.POINTER(C.c_double)) if want_accum else None,
+                     rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    _check(lib.rtx_render_multi(flat.ptr, C.byref(cam), C.byref(cfg), n_gpus, C.byref(frame)))
+    return Screen(w, h, rgb8, accum)
 
 
 def trace_kernel_name(kernel):

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -775,3 +777,5 @@ rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig*
 }
 
 }  // extern "C"
+
+#include "multi.inc"  // rtx_multi_*: one process, several GPUs, one RCCL gather

@@ -1,0 +1,63 @@
+"""rtx_multi_*: several shards / GPUs behind the C ABI, one RCCL gather (replaces the band threads + collect loop of
+render_scene, world.rs:1198-1244).  On the one-GPU box: n_gpus = 1 THROUGH RCCL (ncclCommInitAll + ncclGather with one
+rank), and 2..8 row-interleaved shards rehearsed on that one device; every frame must equal rtx_render's byte for byte."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(rtsr, sid, width, aspect, spp, **opts):
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(sid, **opts)
+    cfg = rtsr.Config.new(aspect, width, spp, 50, 10, seed=7, background=bg)
+    return b, world, cam, cfg, b.flatten(world)
+
+
+def test_one_gpu_through_rccl_equals_rtx_render(rtsr, orc):
+    b, world, cam, cfg, flat = _setup(rtsr, 100, 160, 1.5, 8)
+    single = flat.upload().render(cam, cfg)
+    multi = rtsr.MultiScene(flat, 1)
+    screen = multi.render(cam, cfg)
+    assert screen.stats.used_rccl == 1 and screen.stats.n_devices == 1 and screen.stats.n_shards == 1
+    assert np.array_equal(screen.rgb8, single.rgb8) and np.array_equal(screen.accum, single.accum)
+    # the convenience entry point (create + render + destroy)
+    once = rtsr.render_multi(flat, cam, cfg, 1)
+    assert np.array_equal(once.rgb8, single.rgb8) and np.array_equal(once.accum, single.accum)
+    # and the oracle, for good measure
+    ref, ref8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, rtsr.image_height(cfg), threads=16)
+    assert np.array_equal(screen.accum, ref) and np.array_equal(screen.rgb8, ref8)
+    # the scene stays resident: a second frame with another camera / seed through the same handle
+    cfg2 = rtsr.RtxConfig.from_buffer_copy(cfg)
+    cfg2.seed = 8
+    again = multi.render(cam, cfg2, want_accum=False)
+    assert np.array_equal(again.rgb8, flat.upload().render(cam, cfg2).rgb8)
+
+
+@pytest.mark.parametrize("n_shards,block_rows", [(2, 1), (3, 1), (8, 1), (4, 4), (5, 3)])
+@pytest.mark.parametrize("sid,width,aspect,spp,opts", [(100, 120, 1.5, 6, {}), (6, 64, 1.0, 4, {}), (11, 96, 16.0 / 9.0, 4, {"mesh_triangles": 20000})],
+                         ids=["book1", "book2", "dragon_room"])
+def test_shards_on_one_device_reassemble_the_frame(rtsr, n_shards, block_rows, sid, width, aspect, spp, opts):
+    """All shards on device 0 (the rehearsal mode): the un-tiling kernel and the padded gather layout are the ones the
+    8-GPU path uses; only ncclGather is replaced by a device-to-device copy."""
+    b, world, cam, cfg, flat = _setup(rtsr, sid, width, aspect, spp, **opts)
+    single = flat.upload().render(cam, cfg)
+    multi = rtsr.MultiScene(flat, n_shards, device_ids=[0] * n_shards, block_rows=block_rows)
+    screen = multi.render(cam, cfg)
+    assert screen.stats.used_rccl == 0 and screen.stats.n_shards == n_shards
+    assert np.array_equal(screen.rgb8, single.rgb8)
+    assert np.array_equal(screen.accum, single.accum)
+
+
+def test_multi_errors(rtsr):
+    import torch
+    b, world, cam, cfg, flat = _setup(rtsr, 100, 32, 1.5, 1)
+    n_dev = torch.cuda.device_count()
+    with pytest.raises(rtsr.RtxError) as e:
+        rtsr.MultiScene(flat, n_dev + 1)  # device n_dev does not exist
+    assert e.value.status == rtsr.RTX_EINVAL
+    with pytest.raises(rtsr.RtxError):
+        rtsr.MultiScene(flat, 0)
+    if n_dev >= 1:
+        with pytest.raises(rtsr.RtxError):
+            rtsr.MultiScene(flat, 3, device_ids=[0, 0, n_dev])
