@@ -83,3 +83,51 @@ def test_full_resolution_spot_rows(rtsr, orc, name, sid, width, aspect, spp, opt
     diff = np.abs(full.accum[rows] - ref_accum).max(axis=2)
     assert np.array_equal(full.accum[rows], ref_accum), "%d pixels differ" % int((diff > 0).sum())
     assert np.array_equal(full.rgb8[rows], ref_rgb8)
+
+
+def test_c5_frame_shards_and_full_spp_rows(rtsr, orc):
+    """BASELINE configs[4]: Book-1 final scene at 3840x2160, 2000 spp, tiled over 8 GPUs.
+
+    On one GPU: (a) the 8.3-megapixel frame at 2 spp as ONE shard and as the 8 row-interleaved shards the 8-GPU run
+    uses (rtx_multi rehearsal: same un-tiling kernel and padded gather layout, device-to-device copies instead of
+    ncclGather) -- byte-identical; (b) single image rows at the FULL 2000 spp (a row is a pure function of scene,
+    camera, config and row index) against the CPU oracle: the 67-pass accumulation of a full C5 frame adds nothing a
+    row at full spp does not exercise except the pass loop, which (c) covers on a band of rows with a small sample buffer."""
+    rdist = importlib.import_module("ray-tracing-series-rust_amd.dist")
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(rtsr.SCENE_BOOK1_CANONICAL, camera_aspect=16.0 / 9.0)
+    flat = b.flatten(world)
+    scene = flat.upload()
+    # (a) whole frame, low spp
+    cfg = rtsr.Config.new(16.0 / 9.0, 3840, 2, 50, 10, seed=1, background=bg)
+    h = rtsr.image_height(cfg)
+    assert h == 2160
+    full = scene.render(cam, cfg)
+    assert np.isfinite(full.accum).all() and full.accum.min() >= 0.0
+    shard = (7, 431, 1)  # 5 rows spread over the frame
+    rows = rdist.shard_row_indices(h, shard)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, shard=shard, threads=32)
+    assert np.array_equal(full.accum[rows], ref_accum) and np.array_equal(full.rgb8[rows], ref_rgb8)
+    eight = rtsr.MultiScene(flat, 8, device_ids=[0] * 8).render(cam, cfg)
+    assert eight.stats.n_shards == 8
+    assert np.array_equal(eight.accum, full.accum) and _checksum(eight.rgb8) == _checksum(full.rgb8)
+    del eight
+    # (b) rows at the full 2000 spp
+    cfg_full = rtsr.Config.new(16.0 / 9.0, 3840, 2000, 50, 10, seed=1, background=bg)
+    for j in (3, 1080, 2155):
+        acc, rgb = _render_rows_device(rtsr, scene, cam, cfg_full, (j, h, 1))
+        ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg_full, h, shard=(j, h, 1), threads=32)
+        assert np.array_equal(acc, ref_accum), j
+        assert np.array_equal(rgb, ref_rgb8), j
+    # (c) the pass loop at full spp: 8 rows, sample buffer capped so that the 2000 samples take 67 passes (as a whole C5
+    # frame does with the default 6 GiB buffer: 30 spp per pass)
+    cfg_pass = rtsr.RtxConfig.from_buffer_copy(cfg_full)
+    cfg_pass.sample_buffer_bytes = 8 * 3840 * 24 * 30
+    band = (1, 270, 1)  # rows 1, 271, ... : 8 rows
+    assert rtsr.shard_rows(cfg_pass, band) == 8
+    import torch
+    d_acc = torch.zeros(8 * 3840 * 3, dtype=torch.float64, device="cuda")
+    st = scene.render_device(cam, cfg_pass, shard=band, d_accum=d_acc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, want_stats=True)
+    assert st.passes == 67
+    one_pass, _ = _render_rows_device(rtsr, scene, cam, cfg_full, band)
+    assert np.array_equal(d_acc.cpu().numpy().reshape(8, 3840, 3), one_pass)
