@@ -191,11 +191,12 @@ typedef struct RtxRenderStats {
 /* Trace kernels (all produce identical results; the launcher picks by world shape and LDS budget). */
 enum {
   RTX_KERNEL_SIMPLE = 0,     /* grid-stride, one whole path per thread (also the counting kernel) */
-  RTX_KERNEL_PERSISTENT = 1, /* persistent waves + path regeneration; any world */
+  RTX_KERNEL_PERSISTENT = 1, /* persistent waves + path regeneration, wave-synchronous list scan; any world (A/B partner of WORLD) */
   RTX_KERNEL_STREAM = 2,     /* A/B only */
   RTX_KERNEL_VOTE = 3,       /* worlds that are one BVH: node/leaf voting walk, f32 culling, carry-over */
   RTX_KERNEL_LDS = 4,        /* RTX_KERNEL_VOTE with the geometry resident in LDS (sphere worlds that fit) */
-  RTX_KERNEL_WQ = 5          /* experimental: workgroup-level path queues in LDS */
+  RTX_KERNEL_WQ = 5,         /* experimental (not in the default build): workgroup-level path queues in LDS */
+  RTX_KERNEL_WORLD = 6       /* any world: per-lane scan of the world list, walks of every BVH entry carried over */
 };
 const char* rtx_trace_kernel_name(int32_t kernel);
 /* Blocking; host output buffers.  Renders the whole image on the current device. */

@@ -35,6 +35,7 @@ const char* rtx_trace_kernel_name(int32_t kernel) {
     case RTX_KERNEL_VOTE: return "k_trace_vote";
     case RTX_KERNEL_LDS: return "k_trace_lds";
     case RTX_KERNEL_WQ: return "k_trace_wq";
+    case RTX_KERNEL_WORLD: return "k_trace_world";
     default: return "?";
   }
 }

@@ -15,8 +15,10 @@
 #include <cstdlib>
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <string>
 #include <vector>
 #include "../../../include/rtx_abi.h"
@@ -31,6 +33,7 @@ namespace rtx {
 #define TRACE_CHUNK_DEFAULT 512u
 struct FlatNode4;
 typedef const FlatNode4 FlatNode4Dev;
+struct WorldDesc;
 
 struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
   uint32_t n_nodes, n_refs, n_spheres, n_moving;
@@ -80,6 +83,11 @@ struct DeviceScene {
   bool wq_ok = false;                 // world fits k_trace_wq's 16-bit work items and LDS budget
   uint32_t wq_paths = 0, wq_levels = 0, wq_walkers = 12, wq_batch_min = 48;
   unsigned int* error_word = nullptr;
+  bool world_diag = false;            // RTX_TRACE_KERNEL=world_diag: region counters of k_trace_world on stderr (never timed)
+  uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
+  int world_waves = 3;                // k_trace_world: waves per SIMD its registers are capped for (RTX_WORLD_WAVES = 3 | 4)
+  int world_blocks_per_cu[2][2] = {{1, 1}, {1, 1}};  // [book2 preset / all][binary / wide]
+  const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -169,7 +177,10 @@ __device__ __forceinline__ void flush_counters(const rt::TraceCounters& c, rt::T
 // ------------------------------------------------------------------ kernels
 #include "trace_basic.inc"   // k_trace_simple, k_trace_persistent, k_trace_stream
 #include "trace_vote.inc"    // voting walk, 4-wide tree, k_trace_vote
-#include "trace_wq.inc"      // k_trace_wq (experimental)
+#include "trace_world.inc"   // k_trace_world: any world, per-lane scan of the world list with carried-over walks
+#ifdef RTX_EXPERIMENTAL_KERNELS
+#include "trace_wq.inc"      // k_trace_wq: measured dead end kept for A/B (build with -DRTX_EXPERIMENTAL_KERNELS)
+#endif
 #include "trace_lds.inc"     // k_trace_lds (the headline kernel)
 #include "post_kernels.inc"  // k_reduce_samples, k_tonemap, device self tests
 
@@ -321,6 +332,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         if ((feat & ~P_STATIC_SPHERES) == 0) { if (ds->lds_ring) { LAUNCH_LDS(P_STATIC_SPHERES, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false); } }
         else if (ds->lds_ring) { LAUNCH_LDS(P_SPHERES, true); } else { LAUNCH_LDS(P_SPHERES, false); }
 #undef LAUNCH_LDS
+#ifdef RTX_EXPERIMENTAL_KERNELS
       } else if (ds->force_wq && ds->wq_ok && preset == 0) {
         kernel_used = RTX_KERNEL_WQ;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -355,6 +367,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         HIP_TRY(hipMemcpyAsync(&err, ds->error_word, sizeof(err), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
+#endif
       } else if (ds->vote_ok && preset < 2 && !ds->force_persistent && !(ds->force_stream && ds->single_bvh)) {
         kernel_used = RTX_KERNEL_VOTE;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -397,6 +410,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         }
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
 #undef LAUNCH_VOTE
+#ifdef RTX_EXPERIMENTAL_KERNELS
       } else if (ds->single_bvh && preset < 2 && ds->force_stream) {
         kernel_used = RTX_KERNEL_STREAM;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -410,6 +424,47 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         if (preset == 0) { LAUNCH_STREAM(P_SPHERES); }
         else { LAUNCH_STREAM(P_MESH); }
 #undef LAUNCH_STREAM
+#endif
+      } else if (!ds->force_persistent) {
+        kernel_used = RTX_KERNEL_WORLD;
+        HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
+        const bool wide = ds->nodes4 != nullptr;
+        const bool book2 = (feat & ~P_BOOK2) == 0;
+        const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
+        const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(double);
+        uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[book2 ? 0 : 1][wide ? 1 : 0];
+        uint32_t grid = (uint32_t)(want < resident ? want : resident);
+#define LAUNCH_WORLD(FEAT, WIDEF, WPS)                                                                   \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<FEAT, WIDEF, WPS>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream, \
+                     ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries, \
+                     ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles, \
+                     ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels)
+        if (ds->world_diag && book2 && wide) {
+          if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
+          HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<P_BOOK2, true, 3, true>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream,
+                             ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries,
+                             ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles,
+                             ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->diag);
+          HIP_TRY(hipStreamSynchronize(stream));
+          unsigned long long hd[16];
+          HIP_TRY(hipMemcpy(hd, ds->diag, sizeof(hd), hipMemcpyDeviceToHost));
+          const char* names[8] = {"node_step", "leaf_step", "sweep", "shade(lean)", "regen", "direct_entry(all)", "direct_entry(run)", "shade(rare)"};
+          for (int k = 0; k < 8; ++k)
+            fprintf(stderr, "[world_diag] %-18s executions %llu lanes %llu mean lanes %.2f\n", names[k], hd[2 * k], hd[2 * k + 1],
+                    hd[2 * k] ? (double)hd[2 * k + 1] / (double)hd[2 * k] : 0.0);
+        } else if (ds->world_waves == 4) {
+          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 4); } else { LAUNCH_WORLD(P_BOOK2, false, 4); } }
+          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 4); } else { LAUNCH_WORLD(P_ALL, false, 4); } }
+        } else if (ds->world_waves == 2) {
+          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 2); } else { LAUNCH_WORLD(P_BOOK2, false, 2); } }
+          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 2); } else { LAUNCH_WORLD(P_ALL, false, 2); } }
+        } else {
+          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 3); } else { LAUNCH_WORLD(P_BOOK2, false, 3); } }
+          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 3); } else { LAUNCH_WORLD(P_ALL, false, 3); } }
+        }
+#undef LAUNCH_WORLD
       } else {
         kernel_used = RTX_KERNEL_PERSISTENT;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -516,13 +571,18 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
+#ifdef RTX_EXPERIMENTAL_KERNELS
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[1] = nb;
+#endif
     const char* k = getenv("RTX_TRACE_KERNEL");
     ds->force_simple = (k && strcmp(k, "simple") == 0);
     ds->force_persistent = (k && strcmp(k, "persistent") == 0);
+#ifdef RTX_EXPERIMENTAL_KERNELS
     ds->force_stream = (k && strcmp(k, "stream") == 0);
+#endif
     ds->vote_diag = (k && strcmp(k, "vote_diag") == 0);
+    ds->world_diag = (k && strcmp(k, "world_diag") == 0);
     ds->force_vote = ds->vote_diag || (k && strcmp(k, "vote") == 0);
     {
       const size_t lds_ring = lds + (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE;
@@ -600,6 +660,36 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         if (wd) fprintf(stderr, "[rtx] RTX_WIDE: 4-wide tree %s (%d stack levels)\n", ds->nodes4 ? "on" : "off", ds->wide_levels);
       }
     }
+    {
+      const std::vector<WorldDesc> wd = build_world_desc(fs);
+      const WorldDesc* dptr = nullptr;
+      if ((st = upload_array(ds, wd, &dptr)) != RTX_OK) { free_device_scene(ds); return st; }
+      ds->world_desc = dptr;
+    }
+    {
+      const char* ww = getenv("RTX_WORLD_WAVES");
+      if (ww && atoi(ww) >= 2 && atoi(ww) <= 4) ds->world_waves = atoi(ww);
+      const char* wth = getenv("RTX_WORLD_THRESHOLD");
+      if (wth && atoi(wth) >= 0 && atoi(wth) <= 64) ds->world_threshold = (uint32_t)atoi(wth);
+      for (int wd = 0; wd < 2; ++wd) {
+        const uint32_t levels = (uint32_t)(wd ? ds->wide_levels : fs.max_stack + 1);
+        const size_t wl = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(double);
+        if (wl > 64 * 1024) continue;
+        int n = 0;
+#define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
+        if (ds->world_waves == 4) {
+          if (wd) { WORLD_OCC(P_BOOK2, true, 4, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 4, ds->world_blocks_per_cu[1][1]); }
+          else { WORLD_OCC(P_BOOK2, false, 4, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 4, ds->world_blocks_per_cu[1][0]); }
+        } else if (ds->world_waves == 2) {
+          if (wd) { WORLD_OCC(P_BOOK2, true, 2, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 2, ds->world_blocks_per_cu[1][1]); }
+          else { WORLD_OCC(P_BOOK2, false, 2, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 2, ds->world_blocks_per_cu[1][0]); }
+        } else {
+          if (wd) { WORLD_OCC(P_BOOK2, true, 3, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 3, ds->world_blocks_per_cu[1][1]); }
+          else { WORLD_OCC(P_BOOK2, false, 3, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 3, ds->world_blocks_per_cu[1][0]); }
+        }
+#undef WORLD_OCC
+      }
+    }
     if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes32.size() <= LDSK_MAX_NODES) {
       uint32_t max_count = 0, max_end = 0;
       for (const rt::FlatNode& nd : fs.nodes)
@@ -639,6 +729,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring of %u, %u B of LDS)\n", ds->lds_ok ? "on" : "off",
                       ds->lds_ring ? ds->lds_ring_cap : 0u, ldsk_layout(levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims).total);
     }
+#ifdef RTX_EXPERIMENTAL_KERNELS
     ds->wq_diag = (k && strcmp(k, "wq_diag") == 0);
     ds->force_wq = ds->wq_diag || (k && strcmp(k, "wq") == 0);
     if (ds->single_bvh && (fs.features & ~P_SPHERES) == 0 && fs.nodes.size() <= WQ_MAX_NODES) {
@@ -677,6 +768,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     if (ds->force_wq)
       fprintf(stderr, "[rtx] RTX_TRACE_KERNEL=wq: %s (paths %u, stack levels %u, walkers %u)\n",
               ds->wq_ok ? "applies" : "does NOT apply to this world, default kernel runs", ds->wq_paths, ds->wq_levels, ds->wq_walkers);
+#endif
     // a leaf step costs about (primitives per leaf) x 1.3 node steps for spheres: vote weight 1 for single-primitive
     // leaves, 3 otherwise (measured on C2 / HEAD / C4)
     {

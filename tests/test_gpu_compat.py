@@ -89,7 +89,7 @@ REFERENCE_BVH_CASES = [  # (name, scene id, width, aspect, spp, options, expecte
     ("book1_canonical", 100, 120, 1.5, 6, {}, "k_trace_lds"),
     ("book1_head", 13, 120, 16.0 / 9.0, 6, {}, "k_trace_lds"),
     ("dragon_room", 11, 120, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, "k_trace_vote"),
-    ("book2_final", 6, 80, 1.0, 4, {}, "k_trace_persistent"),
+    ("book2_final", 6, 80, 1.0, 4, {}, "k_trace_world"),
 ]
 
 

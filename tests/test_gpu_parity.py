@@ -82,9 +82,7 @@ VARIANTS = [
     {"RTX_RING": "0"},                      # voting kernel, regeneration per lane (no LDS ring of primary rays)
     {"RTX_RING": "1"},                      # voting kernel + ring (default where LDS allows)
     {"RTX_TRACE_KERNEL": "persistent"},
-    {"RTX_TRACE_KERNEL": "stream"},
     {"RTX_TRACE_KERNEL": "simple"},
-    {"RTX_TRACE_KERNEL": "wq"},             # workgroup LDS path queues (experimental)
     {"RTX_WALK_THRESHOLD": "1", "RTX_LEAF_WEIGHT": "1"},
 ]
 
@@ -138,9 +136,9 @@ def test_tiny_frames(rtsr, orc, width, aspect, spp, depth):
 
 WIDE_CASES = [  # (name, scene id, width, aspect, spp, options, expected kernel)
     ("dragon_room", 11, 144, 16.0 / 9.0, 4, {"mesh_triangles": 20000}, "k_trace_vote"),
-    ("book2_final", 6, 96, 1.0, 6, {}, "k_trace_persistent"),
-    ("cornell_box", 4, 80, 1.0, 6, {}, "k_trace_persistent"),
-    ("nested_lists", 9, 96, 16.0 / 9.0, 4, {}, "k_trace_persistent"),
+    ("book2_final", 6, 96, 1.0, 6, {}, "k_trace_world"),
+    ("cornell_box", 4, 80, 1.0, 6, {}, "k_trace_world"),
+    ("nested_lists", 9, 96, 16.0 / 9.0, 4, {}, "k_trace_world"),
 ]
 
 
