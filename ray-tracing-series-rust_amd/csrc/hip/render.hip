@@ -83,6 +83,7 @@ struct DeviceScene {
   bool wq_ok = false;                 // world fits k_trace_wq's 16-bit work items and LDS budget
   uint32_t wq_paths = 0, wq_levels = 0, wq_walkers = 12, wq_batch_min = 48;
   unsigned int* error_word = nullptr;
+  bool force_world = false;           // RTX_TRACE_KERNEL=world: k_trace_world even where a more special kernel applies (A/B)
   bool world_diag = false;            // RTX_TRACE_KERNEL=world_diag: region counters of k_trace_world on stderr (never timed)
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_waves = 3;                // k_trace_world: waves per SIMD its registers are capped for (RTX_WORLD_WAVES = 3 | 4)
@@ -318,7 +319,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           else { LAUNCH_SIMPLE(P_ALL); }
         }
 #undef LAUNCH_SIMPLE
-      } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream) {
+      } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream && !ds->force_world) {
         kernel_used = RTX_KERNEL_LDS;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims);
@@ -368,7 +369,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         HIP_TRY(hipStreamSynchronize(stream));
         if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
 #endif
-      } else if (ds->vote_ok && preset < 2 && !ds->force_persistent && !(ds->force_stream && ds->single_bvh)) {
+      } else if (ds->vote_ok && preset < 2 && !ds->force_persistent && !ds->force_world && !(ds->force_stream && ds->single_bvh)) {
         kernel_used = RTX_KERNEL_VOTE;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -405,7 +406,22 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
                      (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels, \
                      (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base)
           // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
-          if ((feat & ~P_MESH_ROOM) == 0) { LAUNCH_VOTE_WIDE(P_MESH_ROOM); } else { LAUNCH_VOTE_WIDE(P_MESH); }
+          if (ds->vote_diag && (feat & ~P_MESH_ROOM) == 0) {
+            if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH_ROOM, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
+                               stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
+                               ds->diag, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
+                               (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base);
+            HIP_TRY(hipStreamSynchronize(stream));
+            unsigned long long h[12];
+            HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
+            const char* names[6] = {"outer", "regen", "node_step", "leaf_step", "shade_hit", "shade_all"};
+            for (int k = 0; k < 6; ++k)
+              fprintf(stderr, "[vote_diag] %-10s executions %llu lanes %llu mean lanes %.2f\n", names[k], h[2 * k], h[2 * k + 1],
+                      h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+          }
+          else if ((feat & ~P_MESH_ROOM) == 0) { LAUNCH_VOTE_WIDE(P_MESH_ROOM); } else { LAUNCH_VOTE_WIDE(P_MESH); }
 #undef LAUNCH_VOTE_WIDE
         }
         else { if (ring) { LAUNCH_VOTE(P_MESH, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_MESH, false, false, (unsigned long long*)nullptr); } }
@@ -583,6 +599,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
 #endif
     ds->vote_diag = (k && strcmp(k, "vote_diag") == 0);
     ds->world_diag = (k && strcmp(k, "world_diag") == 0);
+    ds->force_world = ds->world_diag || (k && strcmp(k, "world") == 0);
     ds->force_vote = ds->vote_diag || (k && strcmp(k, "vote") == 0);
     {
       const size_t lds_ring = lds + (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE;
