@@ -51,7 +51,7 @@ class RtxSceneOptions(C.Structure):
 
 
 class RtxBuildOptions(C.Structure):
-    _fields_ = [("max_leaf", C.c_int32), ("sah_bins", C.c_int32), ("reference_bvh", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("max_leaf", C.c_int32), ("sah_bins", C.c_int32), ("reference_bvh", C.c_int32), ("gpu_builder", C.c_int32),
                 ("bvh_seed", C.c_uint64)]
 
 
@@ -59,7 +59,8 @@ class RtxFlatInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_spheres", "n_moving_spheres", "n_rects", "n_triangles", "n_nodes",
                                          "n_refs", "n_entries", "n_top_level", "n_materials", "n_textures",
                                          "n_perlins", "n_images", "n_texels", "total_bytes")] + \
-               [("max_stack", C.c_int32), ("n_bvh", C.c_int32), ("sah_cost", C.c_double)]
+               [("max_stack", C.c_int32), ("n_bvh", C.c_int32), ("sah_cost", C.c_double), ("bvh_build_ms", C.c_double),
+                ("bvh_device_ms", C.c_double)]
 
 
 class RtxFrame(C.Structure):
@@ -343,15 +344,15 @@ class Builder:
         _check(lib.rtx_get_world_cam(self._p, scene_id, C.byref(opt), C.byref(world), C.byref(cam), bg))
         return world.value, cam, (bg[0], bg[1], bg[2])
 
-    def flatten(self, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0):
-        return Flat(self, world, max_leaf, sah_bins, reference_bvh, bvh_seed)
+    def flatten(self, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0, gpu_builder=False):
+        return Flat(self, world, max_leaf, sah_bins, reference_bvh, bvh_seed, gpu_builder)
 
 
 class Flat:
     """Flattened scene in host memory (rtx_flat)."""
 
-    def __init__(self, builder, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0):
-        opt = RtxBuildOptions(max_leaf, sah_bins, 1 if reference_bvh else 0, 0, bvh_seed)
+    def __init__(self, builder, world, max_leaf=0, sah_bins=0, reference_bvh=False, bvh_seed=0, gpu_builder=False):
+        opt = RtxBuildOptions(max_leaf, sah_bins, 1 if reference_bvh else 0, 1 if gpu_builder else 0, bvh_seed)
         p = _VP()
         _check(lib.rtx_flatten(builder.ptr, world, C.byref(opt), C.byref(p)))
         self._p = p

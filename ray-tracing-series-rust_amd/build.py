@@ -18,6 +18,7 @@ APP_PATH = os.path.join(LIB_DIR, "rtx_render")
 
 HIP_SOURCES = [
     "csrc/hip/render.hip",
+    "csrc/hip/lbvh.hip",
     "csrc/hip/abi.cpp",
     "csrc/host/scene_graph.cpp",
     "csrc/host/flatten.cpp",

@@ -180,6 +180,7 @@ rtx_status rtx_flatten(const rtx_builder* b, rtx_handle world, const RtxBuildOpt
     if (options->max_leaf > 0) opt.max_leaf = options->max_leaf;
     if (options->sah_bins > 0) opt.sah_bins = options->sah_bins;
     opt.reference_bvh = options->reference_bvh ? 1 : 0;
+    opt.gpu_builder = options->gpu_builder ? 1 : 0;
     if (options->bvh_seed) opt.bvh_seed = options->bvh_seed;
   }
   rtx_flat* f = new (std::nothrow) rtx_flat();
@@ -208,6 +209,7 @@ rtx_status rtx_flat_info(const rtx_flat* f, RtxFlatInfo* o) {
   o->n_texels = (int64_t)(s.texels.size() / 3);
   o->total_bytes = (int64_t)s.total_bytes();
   o->max_stack = s.max_stack; o->n_bvh = s.n_bvh; o->sah_cost = s.sah_cost;
+  o->bvh_build_ms = s.bvh_build_ms; o->bvh_device_ms = s.bvh_device_ms;
   return RTX_OK;
 }
 

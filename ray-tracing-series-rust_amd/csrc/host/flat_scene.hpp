@@ -28,6 +28,8 @@ struct FlatScene {
   int32_t n_bvh = 0;
   uint32_t features = 0;      // rt::Feature bits reachable in this scene
   double sah_cost = 0.0;      // summed SAH cost of all BVHs (diagnostic)
+  double bvh_build_ms = 0.0;  // wall time of all BVH builds (host or GPU builder)
+  double bvh_device_ms = 0.0; // GPU builder only: device time (HIP events), uploads and downloads included
 
   // pointers into the vectors above (host memory)
   rt::SceneView view() const {
@@ -64,6 +66,9 @@ struct BuildOptions {
   // twice).  Same image, different traversal statistics -- an A/B switch.
   int reference_bvh = 0;
   uint64_t bvh_seed = 1;
+  // 1: BVHs of >= 1024 primitives are built on the current GPU (csrc/hip/lbvh.hip: Morton clusters + radix tree + refit)
+  // instead of by the host SAH builder: same image, a tree of lower quality, built in milliseconds.
+  int gpu_builder = 0;
 };
 
 // Flatten `world` (any Hittable handle of `g`).  Returns false and sets *err when the graph
@@ -78,6 +83,9 @@ bool flatten_scene(const SceneGraph& g, int32_t world, const BuildOptions& opt, 
 int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
                   std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order, int32_t* depth,
                   double* sah_cost);
+// The GPU builder (csrc/hip/lbvh.hip).  Same contract; -1 with *err set when it cannot run (no GPU, allocation failure).
+int32_t build_bvh_gpu(const std::vector<double>& boxes, int max_leaf, std::vector<rt::FlatNode>* nodes,
+                      std::vector<uint32_t>* order, int32_t* depth, double* device_ms, std::string* err);
 // The reference's builder.  `sort_boxes` are the bounding_box(0.0, 0.0) boxes its comparator uses
 // (bvh.rs:27-28), `boxes` the (time0, time1) boxes the node bounds are made of (bvh.rs:71-78).
 int32_t build_bvh_reference(const std::vector<double>& boxes, const std::vector<double>& sort_boxes,

@@ -11,6 +11,7 @@
 //   MEDIUM     := boundary is any of the above except another medium; media only at top level
 // Anything else is reported as unsupported rather than approximated.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include "../core/geometry.hpp"
@@ -218,7 +219,15 @@ struct Flattener {
           for (rt::PrimRef r : refs) has_tri |= rt::primref_type(r) == rt::PRIM_TRIANGLE;
           bo.max_leaf = has_tri ? 2 : 1;
         }
-        root = build_bvh(boxes, bo, &out.nodes, &order, &depth, &out.sah_cost);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (opt.gpu_builder && refs.size() >= 1024) {
+          std::string gerr;
+          root = build_bvh_gpu(boxes, bo.max_leaf, &out.nodes, &order, &depth, &out.bvh_device_ms, &gerr);
+          if (root < 0) { fail("GPU BVH builder: " + gerr); return -1; }
+        } else {
+          root = build_bvh(boxes, bo, &out.nodes, &order, &depth, &out.sah_cost);
+        }
+        out.bvh_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
       rt::FlatEntry e = blank_entry(rt::ENTRY_BVH);
       e.a = root;
