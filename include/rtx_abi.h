@@ -77,6 +77,9 @@ rtx_handle rtx_isotropic(rtx_builder* b, rtx_handle texture);                   
 rtx_handle rtx_sphere(rtx_builder* b, const double center[3], double radius, rtx_handle mat);          /* hit.rs:187-193 */
 rtx_handle rtx_moving_sphere(rtx_builder* b, const double center0[3], const double center1[3],
                              double time0, double time1, double radius, rtx_handle mat);               /* hit.rs:257-273 */
+/* GravitySphere::new(start, time0, radius, mat): the bouncing ball of the video scene; simulates and stores its ~100 002
+ * heights at construction, as the reference does. */
+rtx_handle rtx_gravity_sphere(rtx_builder* b, const double start[3], double time0, double radius, rtx_handle mat); /* hit.rs:340-367 */
 rtx_handle rtx_triangle(rtx_builder* b, const double v0[3], const double v1[3], const double v2[3],
                         rtx_handle mat);                                                                /* hit.rs:96-107  */
 rtx_handle rtx_xy_rect(rtx_builder* b, double x0, double x1, double y0, double y1, double k, rtx_handle mat); /* hit.rs:456-472 */
@@ -161,6 +164,7 @@ typedef struct RtxFlatInfo {
   double sah_cost;
   double bvh_build_ms;  /* wall time of all BVH builds of this flatten (host SAH, reference rule or GPU builder) */
   double bvh_device_ms; /* GPU builder: device time by HIP events, box upload and node download included */
+  int64_t n_gravity_spheres;
 } RtxFlatInfo;
 /* Host only (no GPU needed).  options may be NULL. */
 rtx_status rtx_flatten(const rtx_builder* b, rtx_handle world, const RtxBuildOptions* options,
@@ -245,6 +249,16 @@ void rtx_multi_destroy(rtx_multi* m); /* NULL-safe */
 rtx_status rtx_multi_render(rtx_multi* m, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out, RtxMultiStats* stats);
 /* Convenience: create on devices 0..n_gpus-1 (block_rows 1), render once, destroy. */
 rtx_status rtx_render_multi(const rtx_flat* f, const RtxCamera* cam, const RtxConfig* cfg, int32_t n_gpus, RtxFrame* out);
+
+/* ---- the time-sweep renderer: render_scene_with_time(t0, t1, path, world)  world.rs:1249-1330 ------------------------ */
+/* One frame of the reference's video experiment on a scene that is ALREADY resident on the GPU (many frames, one
+ * upload): 500 x 500, 500 spp, depth 50, background (0.7, 0.8, 1), camera (13,2,3) -> (0,0,0), vfov 20, aspect 1,
+ * aperture 0.1, focus 10, shutter [t0, t1) -- all hard-coded there -- written to `path` as P3 PPM.  The reference
+ * renders it with its THREADS = 11 row bands (world.rs:18,1284), which leaves rows 495..499 black; row_chunk_compat = 1
+ * reproduces that, 0 renders every row.  `overrides` may be NULL; a non-NULL RtxConfig replaces width / spp / depth /
+ * seed (its aspect_ratio, background and threads are ignored) so that tests need not trace 125 M samples per frame. */
+rtx_status rtx_render_scene_with_time(const rtx_scene* s, double t0, double t1, const char* path, int32_t row_chunk_compat,
+                                      const RtxConfig* overrides);
 
 /* ---- image output: Screen::write_to_ppm_file  screen.rs:40-59 ------------------------------ */
 /* rgb8 in the row order above (row 0 = bottom); writes "P3\n{w} {h}\n255\n" then one "r g b" line

@@ -438,6 +438,72 @@ struct MovingSphere : Hittable {  // hit.rs:247-328
     return true;
   }
 };
+struct GravitySphere : Hittable {  // hit.rs:330-444
+  Point3 start;
+  double time0, radius;
+  const Material* mat;
+  std::vector<double> stored;
+  // GravitySphere::new, hit.rs:340-367 (the oracle simulates its own table; the product's comes from scene_graph.cpp)
+  void simulate() {
+    stored.clear();
+    stored.push_back(start.y());
+    const double incr = 0.001;
+    double t = time0, y = start.y(), vel = 0.0;
+    while (t < 100.0) {
+      t += incr;
+      vel -= 0.000001;
+      if (y - 1.0 * radius <= 0.0) vel *= -0.92;
+      y = std::fmax(1.0 * radius, y + vel);
+      stored.push_back(y);
+    }
+  }
+  static size_t as_usize(double x) {  // Rust `as usize`: saturating, NaN -> 0
+    if (!(x == x) || x <= 0.0) return 0;
+    if (x >= 18446744073709551615.0) return ~(size_t)0;
+    return (size_t)x;
+  }
+  Point3 get_center(double time) const {  // hit.rs:369-391
+    const double incr = 0.001;
+    const size_t idx = as_usize(time / incr);
+    if (idx != ~(size_t)0 && idx + 1 <= stored.size()) return Point3(start.x(), stored[idx], start.z());
+    double t = time0, y = start.y(), vel = 0.0;
+    while (t < time) {
+      t += incr;
+      vel -= 0.000001;
+      if (y - 2.0 * radius <= 0.0) vel *= -0.8;
+      y = std::fmax(2.0 * radius, y + vel);
+    }
+    return Point3(start.x(), y, start.z());
+  }
+  bool hit(const Ray& r, double t_min, double t_max, HitRecord* rec, Rng&) const override {  // hit.rs:394-428
+    Point3 cur = get_center(r.time);
+    Vec3 oc = r.origin - cur;
+    double a = r.direction.length_squared();
+    double half_b = oc.dot(r.direction);
+    double c = oc.length_squared() - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = std::sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+      root = (-half_b + sqrtd) / a;
+      if (root < t_min || t_max < root) return false;
+    }
+    double t = root;
+    Point3 p = r.at(t);
+    Vec3 outward_normal = (p - cur) / radius;
+    create_normal_face(r, outward_normal, &rec->normal, &rec->front_face);
+    rec->p = p; rec->t = t; rec->u = 0.0; rec->v = 0.0; rec->mat_ptr = mat;
+    return true;
+  }
+  bool bounding_box(double t0, double t1, Aabb* out) const override {  // hit.rs:430-443
+    Point3 r3(radius, radius, radius);
+    Aabb box0(get_center(t0) - r3, get_center(t0) + r3);
+    Aabb box1(get_center(t1) - r3, get_center(t1) + r3);
+    *out = Aabb::surrounding_box(box0, box1);
+    return true;
+  }
+};
 struct XyRect : Hittable {  // hit.rs:446-509
   double x0, x1, y0, y1, k;
   const Material* mat;
@@ -758,6 +824,12 @@ struct World {
         auto s = std::make_shared<MovingSphere>();
         s->center0 = Point3(o.f[0], o.f[1], o.f[2]); s->center1 = Point3(o.f[3], o.f[4], o.f[5]);
         s->time0 = o.f[6]; s->time1 = o.f[7]; s->radius = o.f[8]; s->mat = material(o.mat);
+        out = s; break;
+      }
+      case rtx::H_GRAVITY_SPHERE: {
+        auto s = std::make_shared<GravitySphere>();
+        s->start = Point3(o.f[0], o.f[1], o.f[2]); s->time0 = o.f[3]; s->radius = o.f[4]; s->mat = material(o.mat);
+        s->simulate();
         out = s; break;
       }
       case rtx::H_TRIANGLE: {  // Triangle::new, hit.rs:96-107

@@ -60,7 +60,7 @@ class RtxFlatInfo(C.Structure):
                                          "n_refs", "n_entries", "n_top_level", "n_materials", "n_textures",
                                          "n_perlins", "n_images", "n_texels", "total_bytes")] + \
                [("max_stack", C.c_int32), ("n_bvh", C.c_int32), ("sah_cost", C.c_double), ("bvh_build_ms", C.c_double),
-                ("bvh_device_ms", C.c_double)]
+                ("bvh_device_ms", C.c_double), ("n_gravity_spheres", C.c_int64)]
 
 
 class RtxFrame(C.Structure):
@@ -109,6 +109,8 @@ ABI = {
     "rtx_sphere": (_H, [_VP, _D3, C.c_double, _H]),
     "rtx_moving_sphere": (_H, [_VP, _D3, _D3, C.c_double, C.c_double, C.c_double, _H]),
     "rtx_triangle": (_H, [_VP, _D3, _D3, _D3, _H]),
+    "rtx_gravity_sphere": (_H, [_VP, _D3, C.c_double, C.c_double, _H]),
+    "rtx_render_scene_with_time": (C.c_int32, [_VP, C.c_double, C.c_double, C.c_char_p, C.c_int32, C.POINTER(RtxConfig)]),
     "rtx_xy_rect": (_H, [_VP] + [C.c_double] * 5 + [_H]),
     "rtx_xz_rect": (_H, [_VP] + [C.c_double] * 5 + [_H]),
     "rtx_yz_rect": (_H, [_VP] + [C.c_double] * 5 + [_H]),
@@ -287,6 +289,9 @@ class Builder:
     def moving_sphere(self, center0, center1, time0, time1, radius, mat):
         return _handle(lib.rtx_moving_sphere(self._p, _v3(center0), _v3(center1), time0, time1, radius, mat))
 
+    def gravity_sphere(self, start, time0, radius, mat):  # GravitySphere::new, hit.rs:340-367
+        return _handle(lib.rtx_gravity_sphere(self._p, _v3(start), time0, radius, mat))
+
     def triangle(self, v0, v1, v2, mat):
         return _handle(lib.rtx_triangle(self._p, _v3(v0), _v3(v1), _v3(v2), mat))
 
@@ -410,6 +415,11 @@ class Scene:
                          rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
         _check(lib.rtx_render(self._p, C.byref(cam), C.byref(cfg), C.byref(frame)))
         return Screen(w, h, rgb8, accum)
+
+    def render_scene_with_time(self, t0, t1, path, row_chunk_compat=True, overrides=None):
+        """render_scene_with_time(t0, t1, path, world) of world.rs:1249-1330 on this resident scene: one 500x500 PPM frame."""
+        _check(lib.rtx_render_scene_with_time(self._p, t0, t1, path.encode(), 1 if row_chunk_compat else 0,
+                                              C.byref(overrides) if overrides is not None else None))
 
     def render_device(self, cam, cfg, shard=None, d_accum=0, d_rgb8=0, stream=0, want_stats=False):
         """Asynchronous render of one shard into DEVICE buffers (raw pointers, e.g. torch .data_ptr())."""

@@ -17,6 +17,7 @@ enum PrimType : uint32_t {
   PRIM_MOVING_SPHERE = 1,  // hit.rs:247-328
   PRIM_RECT = 2,           // hit.rs:446-639 (axis selects Xy/Xz/Yz)
   PRIM_TRIANGLE = 3,       // hit.rs:87-178
+  PRIM_GRAVITY_SPHERE = 4, // hit.rs:330-444 (the bouncing ball of the video scene)
 };
 
 // A primitive reference: type in the top 3 bits, index into that type's array below.
@@ -35,6 +36,17 @@ struct FlatMovingSphere {  // 80 B
   double time0, time1, radius;
   int32_t mat;
   int32_t pad;
+};
+// hit.rs:330-336.  The ball's height lives in a table of its own (GravitySphere::new simulates 100 time units in steps of
+// 0.001 and stores every height: ~100 002 doubles per ball); times past the table fall back to the reference's second,
+// slightly different simulation loop (hit.rs:378-389).
+struct FlatGravitySphere {  // 64 B
+  double sx, sy, sz;   // start
+  double time0, radius;
+  int32_t mat;
+  int32_t pad;
+  int64_t table_first; // index into SceneView::gravity_y
+  int64_t table_len;
 };
 enum RectAxis : int32_t { RECT_XY = 0, RECT_XZ = 1, RECT_YZ = 2 };
 struct FlatRect {  // 48 B.  (a0,a1,b0,b1,k) are the constructor's (x0,x1,y0,y1,k).
@@ -162,6 +174,8 @@ struct SceneView {
   // (-inf, +inf) for every other slot: lets the list scan skip a primitive test no lane of the wave can pass
   // (core/cull32.hpp: conservative, cannot change a result).  May be null.
   const float* top_box32;
+  const FlatGravitySphere* gravity_spheres;
+  const double* gravity_y;  // the height tables of all gravity spheres, one after another
   int32_t n_top_level;
   int32_t max_stack;  // deepest traversal stack any BVH of this scene needs
   uint32_t features;  // Feature bits the scene can reach
@@ -187,13 +201,14 @@ enum Feature : uint32_t {
   F_LAMBERTIAN = 1u << 9, F_METAL = 1u << 10, F_DIELECTRIC = 1u << 11, F_LIGHT = 1u << 12,
   F_ISOTROPIC = 1u << 13,
   F_CHECKER = 1u << 14, F_NOISE = 1u << 15, F_IMAGE = 1u << 16,
-  F_ALL = (1u << 17) - 1u,
+  F_GRAVITY_SPHERE = 1u << 17,
+  F_ALL = (1u << 18) - 1u,
 };
 
 // Work counters for the algorithmic-bytes model.
 struct TraceCounters {
   unsigned long long box_tests;      // reference-equivalent "node visits" (one Aabb::hit each)
-  unsigned long long sphere_tests, moving_sphere_tests, rect_tests, triangle_tests;
+  unsigned long long sphere_tests, moving_sphere_tests, rect_tests, triangle_tests;  // gravity spheres count as moving spheres
   unsigned long long scatters;       // material evaluations
   unsigned long long texels;         // image texel fetches
   unsigned long long perlin_calls;   // Perlin::noise calls (8 gradient fetches each)

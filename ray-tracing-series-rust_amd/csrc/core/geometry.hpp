@@ -56,6 +56,27 @@ RT_HD Point3 moving_sphere_center(const FlatMovingSphere& s, double time) {
   return c0 + ((time - s.time0) / (s.time1 - s.time0)) * (c1 - c0);
 }
 
+// GravitySphere::get_center (hit.rs:369-391), literally: the table when `(time / incr) as usize + 1 <= stored.len()`
+// (a saturating cast: negative or NaN times index entry 0), otherwise the brute-force loop with its own constants
+// (2 x radius, restitution 0.8 -- the reference's "radius x2 bug" comment).
+RT_HD Point3 gravity_sphere_center(const FlatGravitySphere& s, const double* table, double time) {
+  const double incr = 0.001;
+  const double q = time / incr;
+  uint64_t idx;  // Rust `as usize`: saturating, NaN -> 0
+  if (!(q == q) || q <= 0.0) idx = 0;
+  else if (q >= 18446744073709551615.0) idx = ~0ull;
+  else idx = (uint64_t)q;
+  if (idx < ~0ull && idx + 1 <= (uint64_t)s.table_len) return v3(s.sx, table[s.table_first + (int64_t)idx], s.sz);
+  double t = s.time0, y = s.sy, vel = 0.0;
+  while (t < time) {
+    t += incr;
+    vel -= 0.000001;
+    if (y - 2.0 * s.radius <= 0.0) vel *= -0.8;
+    y = rt_fmax(2.0 * s.radius, y + vel);
+  }
+  return v3(s.sx, y, s.sz);
+}
+
 // Shared by Sphere::hit (hit.rs:204-222) and MovingSphere::hit (hit.rs:282-300).
 RT_HD bool sphere_root(Point3 center, double radius, const Ray& r, double t_min, double t_max,
                        double* t_out) {
@@ -120,23 +141,28 @@ RT_HD bool prim_t(const SceneView& sv, PrimRef ref, const Ray& r, double t_min, 
                   double* t_out, TraceCounters* cnt) {
   uint32_t idx = primref_index(ref);
   uint32_t type = primref_type(ref);
-  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE)))) {
+  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     if (COUNT) cnt->sphere_tests++;
     const FlatSphere& s = sv.spheres[idx];
     return sphere_root(v3(s.cx, s.cy, s.cz), s.radius, r, t_min, t_max, t_out);
   }
-  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE)))) {
+  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     if (COUNT) cnt->moving_sphere_tests++;
     const FlatMovingSphere& s = sv.moving_spheres[idx];
     return sphere_root(moving_sphere_center(s, r.time), s.radius, r, t_min, t_max, t_out);
   }
-  if ((F & F_RECT) && (type == PRIM_RECT || !(F & F_TRIANGLE))) {
+  if ((F & F_RECT) && (type == PRIM_RECT || !(F & (F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     if (COUNT) cnt->rect_tests++;
     return rect_t(sv.rects[idx], r, t_min, t_max, t_out);
   }
-  if (F & F_TRIANGLE) {
+  if ((F & F_TRIANGLE) && (type == PRIM_TRIANGLE || !(F & F_GRAVITY_SPHERE))) {
     if (COUNT) cnt->triangle_tests++;
     return triangle_t(sv.triangles[idx], r, t_min, t_max, t_out);
+  }
+  if (F & F_GRAVITY_SPHERE) {  // hit.rs:394-412
+    if (COUNT) cnt->moving_sphere_tests++;
+    const FlatGravitySphere& s = sv.gravity_spheres[idx];
+    return sphere_root(gravity_sphere_center(s, sv.gravity_y, r.time), s.radius, r, t_min, t_max, t_out);
   }
   return false;
 }
@@ -148,7 +174,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
   uint32_t type = primref_type(ref);
   rec->t = t;
   rec->p = ray_at(r, t);
-  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE)))) {
+  if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     // hit.rs:222-236
     const FlatSphere& s = sv.spheres[idx];
     Vec3 outward = (rec->p - v3(s.cx, s.cy, s.cz)) / s.radius;
@@ -160,7 +186,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     }
     return;
   }
-  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE)))) {
+  if ((F & F_MOVING_SPHERE) && (type == PRIM_MOVING_SPHERE || !(F & (F_RECT | F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     // hit.rs:301-314 (u = v = 0)
     const FlatMovingSphere& s = sv.moving_spheres[idx];
     Vec3 outward = (rec->p - moving_sphere_center(s, r.time)) / s.radius;
@@ -169,7 +195,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     rec->u = 0.0; rec->v = 0.0;
     return;
   }
-  if ((F & F_RECT) && (type == PRIM_RECT || !(F & F_TRIANGLE))) {
+  if ((F & F_RECT) && (type == PRIM_RECT || !(F & (F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     // hit.rs:486-500, 551-565, 616-630
     const FlatRect& q = sv.rects[idx];
     rec->u = 0.0; rec->v = 0.0;
@@ -195,12 +221,21 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     rec->mat = q.mat;
     return;
   }
-  if (F & F_TRIANGLE) {
+  if ((F & F_TRIANGLE) && (type == PRIM_TRIANGLE || !(F & F_GRAVITY_SPHERE))) {
     // hit.rs:151-161 (u = v = 1)
     const FlatTriangle& tr = sv.triangles[idx];
     create_normal_face(r, load_v3(tr.normal), &rec->normal, &rec->front_face);
     rec->mat = tr.mat;
     rec->u = 1.0; rec->v = 1.0;
+    return;
+  }
+  if (F & F_GRAVITY_SPHERE) {
+    // hit.rs:413-428 (u = v = 0)
+    const FlatGravitySphere& s = sv.gravity_spheres[idx];
+    Vec3 outward = (rec->p - gravity_sphere_center(s, sv.gravity_y, r.time)) / s.radius;
+    create_normal_face(r, outward, &rec->normal, &rec->front_face);
+    rec->mat = s.mat;
+    rec->u = 0.0; rec->v = 0.0;
   }
 }
 

@@ -62,6 +62,10 @@ rtx_handle rtx_diffuse_light(rtx_builder* b, rtx_handle tex) { NEED_BUILDER(b); 
 rtx_handle rtx_isotropic(rtx_builder* b, rtx_handle tex) { NEED_BUILDER(b); return checked(b, b->graph.isotropic(tex)); }
 
 rtx_handle rtx_sphere(rtx_builder* b, const double c[3], double r, rtx_handle mat) { NEED_BUILDER(b); if (!c) { set_error("NULL center"); return -1; } return checked(b, b->graph.sphere(c, r, mat)); }
+rtx_handle rtx_gravity_sphere(rtx_builder* b, const double start[3], double time0, double radius, rtx_handle mat) {
+  if (!b || !start) { set_error("rtx_gravity_sphere: NULL argument"); return -1; }
+  return checked(b, b->graph.gravity_sphere(start, time0, radius, mat));
+}
 rtx_handle rtx_moving_sphere(rtx_builder* b, const double c0[3], const double c1[3], double t0, double t1, double r, rtx_handle mat) {
   NEED_BUILDER(b);
   if (!c0 || !c1) { set_error("NULL center"); return -1; }
@@ -210,6 +214,7 @@ rtx_status rtx_flat_info(const rtx_flat* f, RtxFlatInfo* o) {
   o->total_bytes = (int64_t)s.total_bytes();
   o->max_stack = s.max_stack; o->n_bvh = s.n_bvh; o->sah_cost = s.sah_cost;
   o->bvh_build_ms = s.bvh_build_ms; o->bvh_device_ms = s.bvh_device_ms;
+  o->n_gravity_spheres = (int64_t)s.gravity_spheres.size();
   return RTX_OK;
 }
 

@@ -86,8 +86,7 @@ struct DeviceScene {
   bool force_world = false;           // RTX_TRACE_KERNEL=world: k_trace_world even where a more special kernel applies (A/B)
   bool world_diag = false;            // RTX_TRACE_KERNEL=world_diag: region counters of k_trace_world on stderr (never timed)
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
-  int world_waves = 3;                // k_trace_world: waves per SIMD its registers are capped for (RTX_WORLD_WAVES = 3 | 4)
-  int world_blocks_per_cu[2][2] = {{1, 1}, {1, 1}};  // [book2 preset / all][binary / wide]
+  int world_blocks_per_cu[3][2] = {{1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
 };
 
@@ -441,15 +440,16 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         else { LAUNCH_STREAM(P_MESH); }
 #undef LAUNCH_STREAM
 #endif
-      } else if (!ds->force_persistent) {
+      } else if (!ds->force_persistent || (feat & rt::F_GRAVITY_SPHERE)) {
         kernel_used = RTX_KERNEL_WORLD;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         const bool wide = ds->nodes4 != nullptr;
         const bool book2 = (feat & ~P_BOOK2) == 0;
+        const bool has_gravity = (feat & rt::F_GRAVITY_SPHERE) != 0;
         const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
         const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(double);
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
-        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[book2 ? 0 : 1][wide ? 1 : 0];
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : 1)][wide ? 1 : 0];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
 #define LAUNCH_WORLD(FEAT, WIDEF, WPS)                                                                   \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<FEAT, WIDEF, WPS>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream, \
@@ -470,15 +470,12 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           for (int k = 0; k < 8; ++k)
             fprintf(stderr, "[world_diag] %-18s executions %llu lanes %llu mean lanes %.2f\n", names[k], hd[2 * k], hd[2 * k + 1],
                     hd[2 * k] ? (double)hd[2 * k + 1] / (double)hd[2 * k] : 0.0);
-        } else if (ds->world_waves == 4) {
-          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 4); } else { LAUNCH_WORLD(P_BOOK2, false, 4); } }
-          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 4); } else { LAUNCH_WORLD(P_ALL, false, 4); } }
-        } else if (ds->world_waves == 2) {
-          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 2); } else { LAUNCH_WORLD(P_BOOK2, false, 2); } }
-          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 2); } else { LAUNCH_WORLD(P_ALL, false, 2); } }
+        } else if (has_gravity) {  // the bouncing-ball scene: the instantiation that carries GravitySphere code
+          if (wide) { LAUNCH_WORLD(P_ALL, true, 3); } else { LAUNCH_WORLD(P_ALL, false, 3); }
+        } else if (book2) {
+          if (wide) { LAUNCH_WORLD(P_BOOK2, true, 3); } else { LAUNCH_WORLD(P_BOOK2, false, 3); }
         } else {
-          if (book2) { if (wide) { LAUNCH_WORLD(P_BOOK2, true, 3); } else { LAUNCH_WORLD(P_BOOK2, false, 3); } }
-          else { if (wide) { LAUNCH_WORLD(P_ALL, true, 3); } else { LAUNCH_WORLD(P_ALL, false, 3); } }
+          if (wide) { LAUNCH_WORLD(P_ANY, true, 3); } else { LAUNCH_WORLD(P_ANY, false, 3); }
         }
 #undef LAUNCH_WORLD
       } else {
@@ -502,11 +499,11 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
           resident = (uint64_t)ds->n_cu * (uint64_t)ds->wide_pers_blocks_per_cu[preset];
           grid = (uint32_t)(want < resident ? want : resident);
           if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, true, wv, wide_lds); }
-          else { LAUNCH_PERSISTENT(P_ALL, true, wv, wide_lds); }
+          else { LAUNCH_PERSISTENT(P_ANY, true, wv, wide_lds); }
         }
         else if (preset == 0) { LAUNCH_PERSISTENT(P_SPHERES, false, pv, lds_bytes); }
         else if (preset == 1) { LAUNCH_PERSISTENT(P_MESH, false, pv, lds_bytes); }
-        else { LAUNCH_PERSISTENT(P_ALL, false, pv, lds_bytes); }
+        else { LAUNCH_PERSISTENT(P_ANY, false, pv, lds_bytes); }
 #undef LAUNCH_PERSISTENT
       }
       HIP_TRY(hipGetLastError());
@@ -572,7 +569,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
   UP(spheres, spheres) UP(moving_spheres, moving_spheres) UP(rects, rects) UP(triangles, triangles)
   UP(nodes, nodes) UP(nodes32, nodes32) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
   UP(materials, materials) UP(textures, textures) UP(perlins, perlins) UP(images, images) UP(texels, texels)
-  UP(top_box32, top_box32)
+  UP(top_box32, top_box32) UP(gravity_spheres, gravity_spheres) UP(gravity_y, gravity_y)
 #undef UP
   v.n_top_level = (int32_t)fs.top_level.size();
   v.max_stack = fs.max_stack;
@@ -586,7 +583,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_SPHERES, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_MESH, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[1] = nb;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ALL, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_persistent<P_ANY, false>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->blocks_per_cu[2] = nb;
 #ifdef RTX_EXPERIMENTAL_KERNELS
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_SPHERES>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[0] = nb;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_stream<P_MESH>, TRACE_BLOCK, lds) == hipSuccess && nb > 0) ds->stream_blocks_per_cu[1] = nb;
@@ -666,7 +663,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         if (ok) {
           int n1 = 0, n2 = 0;
           if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_trace_persistent<P_MESH, true>, TRACE_BLOCK, wide_lds) == hipSuccess && n1 > 0) ds->wide_pers_blocks_per_cu[1] = n1;
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_trace_persistent<P_ALL, true>, TRACE_BLOCK, wide_lds) == hipSuccess && n2 > 0) ds->wide_pers_blocks_per_cu[2] = n2;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_trace_persistent<P_ANY, true>, TRACE_BLOCK, wide_lds) == hipSuccess && n2 > 0) ds->wide_pers_blocks_per_cu[2] = n2;
           ok = n1 > 0 && n2 > 0;
         }
         if (ok) {
@@ -684,8 +681,6 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       ds->world_desc = dptr;
     }
     {
-      const char* ww = getenv("RTX_WORLD_WAVES");
-      if (ww && atoi(ww) >= 2 && atoi(ww) <= 4) ds->world_waves = atoi(ww);
       const char* wth = getenv("RTX_WORLD_THRESHOLD");
       if (wth && atoi(wth) >= 0 && atoi(wth) <= 64) ds->world_threshold = (uint32_t)atoi(wth);
       for (int wd = 0; wd < 2; ++wd) {
@@ -694,16 +689,8 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
         if (wl > 64 * 1024) continue;
         int n = 0;
 #define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
-        if (ds->world_waves == 4) {
-          if (wd) { WORLD_OCC(P_BOOK2, true, 4, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 4, ds->world_blocks_per_cu[1][1]); }
-          else { WORLD_OCC(P_BOOK2, false, 4, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 4, ds->world_blocks_per_cu[1][0]); }
-        } else if (ds->world_waves == 2) {
-          if (wd) { WORLD_OCC(P_BOOK2, true, 2, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 2, ds->world_blocks_per_cu[1][1]); }
-          else { WORLD_OCC(P_BOOK2, false, 2, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 2, ds->world_blocks_per_cu[1][0]); }
-        } else {
-          if (wd) { WORLD_OCC(P_BOOK2, true, 3, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ALL, true, 3, ds->world_blocks_per_cu[1][1]); }
-          else { WORLD_OCC(P_BOOK2, false, 3, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ALL, false, 3, ds->world_blocks_per_cu[1][0]); }
-        }
+        if (wd) { WORLD_OCC(P_BOOK2, true, 3, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, 3, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, 3, ds->world_blocks_per_cu[2][1]); }
+        else { WORLD_OCC(P_BOOK2, false, 3, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ANY, false, 3, ds->world_blocks_per_cu[1][0]); WORLD_OCC(P_ALL, false, 3, ds->world_blocks_per_cu[2][0]); }
 #undef WORLD_OCC
       }
     }
@@ -886,5 +873,35 @@ rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig*
 }
 
 }  // extern "C"
+
+// render_scene_with_time (world.rs:1249-1330): one frame of the video experiment on a scene that stays resident.
+extern "C" rtx_status rtx_render_scene_with_time(const rtx_scene* s, double t0, double t1, const char* path,
+                                                 int32_t row_chunk_compat, const RtxConfig* overrides) {
+  using namespace rtx;
+  if (!s || !path) { set_error("rtx_render_scene_with_time: NULL argument"); return RTX_EINVAL; }
+  // world.rs:1252-1275: everything about the frame is a constant there
+  const double lookfrom[3] = {13, 2, 3}, lookat[3] = {0, 0, 0}, vup[3] = {0, 1, 0};
+  RtxCamera cam;
+  rtx_status st = rtx_camera_new(lookfrom, lookat, vup, 20.0, 1.0, 0.1, 10.0, t0, t1, &cam);
+  if (st != RTX_OK) return st;  // t0 >= t1: gen_range(t0..t1) panics in the reference
+  RtxConfig cfg;
+  st = rtx_config_new(1.0, 500, 500, 50, 11, &cfg);  // THREADS = 11 (world.rs:18)
+  if (st != RTX_OK) return st;
+  cfg.background[0] = 0.7; cfg.background[1] = 0.8; cfg.background[2] = 1.0;
+  cfg.row_chunk_compat = row_chunk_compat ? 1 : 0;
+  if (overrides) {
+    if (overrides->image_width > 0) cfg.image_width = overrides->image_width;
+    if (overrides->samples_per_pixel > 0) cfg.samples_per_pixel = overrides->samples_per_pixel;
+    if (overrides->max_depth > 0) cfg.max_depth = overrides->max_depth;
+    cfg.seed = overrides->seed;
+    cfg.sample_buffer_bytes = overrides->sample_buffer_bytes;
+  }
+  const size_t npix = (size_t)cfg.image_width * (size_t)rtx_image_height(&cfg);
+  std::vector<uint8_t> rgb(npix * 3);
+  RtxFrame frame = {nullptr, rgb.data()};
+  st = rtx_render(s, &cam, &cfg, &frame);
+  if (st != RTX_OK) return st;
+  return rtx_write_ppm(path, cfg.image_width, rtx_image_height(&cfg), rgb.data());  // screen.write_to_ppm_file(path)
+}
 
 #include "multi.inc"  // rtx_multi_*: one process, several GPUs, one RCCL gather

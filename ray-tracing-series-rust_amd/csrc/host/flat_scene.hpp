@@ -24,6 +24,8 @@ struct FlatScene {
   std::vector<rt::FlatImage> images;
   std::vector<double> texels;
   std::vector<float> top_box32;  // 6 per top-level slot (SceneView::top_box32)
+  std::vector<rt::FlatGravitySphere> gravity_spheres;
+  std::vector<double> gravity_y;
   int32_t max_stack = 0;      // deepest BVH (number of stacked far children a walk can hold)
   int32_t n_bvh = 0;
   uint32_t features = 0;      // rt::Feature bits reachable in this scene
@@ -49,6 +51,8 @@ struct FlatScene {
     v.images = images.data();
     v.texels = texels.data();
     v.top_box32 = top_box32.empty() ? nullptr : top_box32.data();
+    v.gravity_spheres = gravity_spheres.data();
+    v.gravity_y = gravity_y.data();
     v.n_top_level = (int32_t)top_level.size();
     v.max_stack = max_stack;
     v.features = features;

@@ -24,6 +24,7 @@ using rt::Vec3;
 size_t FlatScene::total_bytes() const {
   return spheres.size() * sizeof(rt::FlatSphere) + moving_spheres.size() * sizeof(rt::FlatMovingSphere) +
          rects.size() * sizeof(rt::FlatRect) + triangles.size() * sizeof(rt::FlatTriangle) +
+         gravity_spheres.size() * sizeof(rt::FlatGravitySphere) + gravity_y.size() * sizeof(double) +
          nodes.size() * sizeof(rt::FlatNode) + nodes32.size() * sizeof(rt::FlatNode32) + refs.size() * sizeof(rt::PrimRef) +
          entries.size() * sizeof(rt::FlatEntry) + top_level.size() * sizeof(int32_t) +
          materials.size() * sizeof(rt::FlatMaterial) + textures.size() * sizeof(rt::FlatTexture) +
@@ -49,7 +50,7 @@ struct Flattener {
 
   static bool is_prim(int32_t kind) {
     return kind == H_SPHERE || kind == H_MOVING_SPHERE || kind == H_TRIANGLE || kind == H_XY_RECT ||
-           kind == H_XZ_RECT || kind == H_YZ_RECT;
+           kind == H_XZ_RECT || kind == H_YZ_RECT || kind == H_GRAVITY_SPHERE;
   }
 
   rt::PrimRef emit_rect(int32_t axis, double a0, double a1, double b0, double b1, double k, int32_t mat) {
@@ -85,6 +86,16 @@ struct Flattener {
         t.mat = o.mat; t.pad = 0;
         out.triangles.push_back(t);
         ref = rt::make_primref(rt::PRIM_TRIANGLE, (uint32_t)out.triangles.size() - 1);
+        break;
+      }
+      case H_GRAVITY_SPHERE: {
+        rt::FlatGravitySphere s;
+        s.sx = o.f[0]; s.sy = o.f[1]; s.sz = o.f[2]; s.time0 = o.f[3]; s.radius = o.f[4]; s.mat = o.mat; s.pad = 0;
+        s.table_first = (int64_t)out.gravity_y.size();
+        s.table_len = (int64_t)o.table.size();
+        out.gravity_y.insert(out.gravity_y.end(), o.table.begin(), o.table.end());
+        out.gravity_spheres.push_back(s);
+        ref = rt::make_primref(rt::PRIM_GRAVITY_SPHERE, (uint32_t)out.gravity_spheres.size() - 1);
         break;
       }
       case H_XY_RECT: ref = emit_rect(rt::RECT_XY, o.f[0], o.f[1], o.f[2], o.f[3], o.f[4], o.mat); break;
@@ -137,6 +148,15 @@ struct Flattener {
         const rt::FlatMovingSphere& s = out.moving_spheres[idx];
         Vec3 r = rt::v3(s.radius, s.radius, s.radius);
         Vec3 ca = rt::moving_sphere_center(s, time0), cb = rt::moving_sphere_center(s, time1);
+        Vec3 lo0 = ca - r, hi0 = ca + r, lo1 = cb - r, hi1 = cb + r;
+        b[0] = std::fmin(lo0.x, lo1.x); b[1] = std::fmin(lo0.y, lo1.y); b[2] = std::fmin(lo0.z, lo1.z);
+        b[3] = std::fmax(hi0.x, hi1.x); b[4] = std::fmax(hi0.y, hi1.y); b[5] = std::fmax(hi0.z, hi1.z);
+        break;
+      }
+      case rt::PRIM_GRAVITY_SPHERE: {  // hit.rs:430-443: union of the boxes at time0 and time1 (NOT of the trajectory between)
+        const rt::FlatGravitySphere& s = out.gravity_spheres[idx];
+        Vec3 r = rt::v3(s.radius, s.radius, s.radius);
+        Vec3 ca = rt::gravity_sphere_center(s, out.gravity_y.data(), time0), cb = rt::gravity_sphere_center(s, out.gravity_y.data(), time1);
         Vec3 lo0 = ca - r, hi0 = ca + r, lo1 = cb - r, hi1 = cb + r;
         b[0] = std::fmin(lo0.x, lo1.x); b[1] = std::fmin(lo0.y, lo1.y); b[2] = std::fmin(lo0.z, lo1.z);
         b[3] = std::fmax(hi0.x, hi1.x); b[4] = std::fmax(hi0.y, hi1.y); b[5] = std::fmax(hi0.z, hi1.z);
@@ -373,6 +393,7 @@ struct Flattener {
     if (!out.moving_spheres.empty()) f |= rt::F_MOVING_SPHERE;
     if (!out.rects.empty()) f |= rt::F_RECT;
     if (!out.triangles.empty()) f |= rt::F_TRIANGLE;
+    if (!out.gravity_spheres.empty()) f |= rt::F_GRAVITY_SPHERE;
     for (const rt::FlatEntry& e : out.entries) {
       if (e.kind == rt::ENTRY_PRIM) f |= rt::F_PRIM_ENTRY;
       else if (e.kind == rt::ENTRY_GROUP) f |= rt::F_GROUP;
@@ -402,7 +423,7 @@ struct Flattener {
       const rt::FlatEntry& e = out.entries[out.top_level[k]];
       if (e.kind != rt::ENTRY_PRIM) continue;
       const rt::PrimRef ref = (rt::PrimRef)e.a;
-      if (rt::primref_type(ref) == rt::PRIM_MOVING_SPHERE) continue;
+      if (rt::primref_type(ref) == rt::PRIM_MOVING_SPHERE || rt::primref_type(ref) == rt::PRIM_GRAVITY_SPHERE) continue;
       double b[6];
       prim_box(ref, 0.0, 0.0, b);
       for (int a = 0; a < 3; ++a) {

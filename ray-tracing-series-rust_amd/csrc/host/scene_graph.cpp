@@ -1,6 +1,7 @@
 // Scene graph construction (see scene_graph.hpp).  Field packing per kind:
 //   H_SPHERE          f[0..2] center, f[3] radius
 //   H_MOVING_SPHERE   f[0..2] center0, f[3..5] center1, f[6] time0, f[7] time1, f[8] radius
+//   H_GRAVITY_SPHERE  f[0..2] start, f[3] time0, f[4] radius; table = stored heights
 //   H_TRIANGLE        f[0..2] v0, f[3..5] v1, f[6..8] v2, f[9..11] stored unit normal
 //   H_XY/XZ/YZ_RECT   f[0] x0, f[1] x1, f[2] y0, f[3] y1, f[4] k   (constructor names)
 //   H_RECT_PRISM      f[0..2] p0, f[3..5] p1
@@ -173,6 +174,24 @@ int32_t SceneGraph::moving_sphere(const double c0[3], const double c1[3], double
   GHittable h = make_h(H_MOVING_SPHERE, mat);
   for (int i = 0; i < 3; ++i) { h.f[i] = c0[i]; h.f[3 + i] = c1[i]; }
   h.f[6] = t0; h.f[7] = t1; h.f[8] = radius;
+  hittables.push_back(std::move(h));
+  return (int32_t)hittables.size() - 1;
+}
+// GravitySphere::new (hit.rs:340-367): the height table is simulated here exactly as the reference does it.
+int32_t SceneGraph::gravity_sphere(const double start[3], double time0, double radius, int32_t mat) {
+  if (!valid_material(mat)) { error = "gravity_sphere: bad material handle"; return -1; }
+  GHittable h = make_h(H_GRAVITY_SPHERE, mat);
+  h.f[0] = start[0]; h.f[1] = start[1]; h.f[2] = start[2]; h.f[3] = time0; h.f[4] = radius;
+  h.table.push_back(start[1]);
+  const double incr = 0.001;
+  double t = time0, y = start[1], vel = 0.0;
+  while (t < 100.0) {
+    t += incr;
+    vel -= 0.000001;
+    if (y - 1.0 * radius <= 0.0) vel *= -0.92;
+    y = rt::rt_fmax(1.0 * radius, y + vel);
+    h.table.push_back(y);
+  }
   hittables.push_back(std::move(h));
   return (int32_t)hittables.size() - 1;
 }

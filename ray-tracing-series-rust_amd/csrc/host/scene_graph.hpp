@@ -28,7 +28,8 @@ enum HittableKind : int32_t {
   H_BVH = 8,             // BvhNode::from_list(list, time0, time1)              bvh.rs:85-93
   H_TRANSLATE = 9,       // Translate::new(offset, obj)                         hit.rs:793-798
   H_ROTATE_Y = 10,       // RotateY::new(angle_deg, obj)                        hit.rs:843-888
-  H_CONSTANT_MEDIUM = 11 // ConstantMedium::from_color(color, density, boundary) hit.rs:945-951
+  H_CONSTANT_MEDIUM = 11,// ConstantMedium::from_color(color, density, boundary) hit.rs:945-951
+  H_GRAVITY_SPHERE = 12  // GravitySphere::new(start, time0, radius, mat)         hit.rs:340-367
 };
 
 struct GHittable {
@@ -36,6 +37,7 @@ struct GHittable {
   int32_t mat;                    // material handle (-1 if none)
   double f[12];                   // constructor numbers, kind specific (see scene_graph.cpp)
   std::vector<int32_t> children;  // LIST/BVH: objects in add() order; wrappers: the one child
+  std::vector<double> table;      // GRAVITY_SPHERE: `stored`, the simulated heights (hit.rs:346-359)
 };
 
 struct GMaterial {
@@ -83,6 +85,7 @@ struct SceneGraph {
   // --- hittables ---
   int32_t sphere(const double c[3], double radius, int32_t mat);
   int32_t moving_sphere(const double c0[3], const double c1[3], double t0, double t1, double radius, int32_t mat);
+  int32_t gravity_sphere(const double start[3], double time0, double radius, int32_t mat);
   int32_t triangle(const double v0[3], const double v1[3], const double v2[3], int32_t mat);
   int32_t rect(int32_t kind, double a0, double a1, double b0, double b1, double k, int32_t mat);
   int32_t rect_prism(const double p0[3], const double p1[3], int32_t mat);

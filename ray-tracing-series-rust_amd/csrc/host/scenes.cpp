@@ -3,6 +3,7 @@
 // random draws come from the builder's seeded scene stream instead of thread_rng().
 #include "scenes.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include "../core/rt_math.hpp"
@@ -107,6 +108,44 @@ int32_t gen_random_scene(S& s) {
   s.g.list_add(list, s.sphere(v3(-4, 1, 0), 1.0, s.lamb(0.4, 0.2, 0.1)));
   s.g.list_add(list, s.sphere(v3(4, 1, 0), 1.0, s.metal(v3(0.7, 0.6, 0.5), 0.0)));
   return s.g.bvh_from_list(list, 0.0, 10.0);
+}
+
+// world.rs:169-244 (gen_random_scene_moving): the bouncing-ball scene of the video experiment.
+int32_t gen_random_scene_moving(S& s) {
+  const double max_time = 100.0;
+  int32_t list = s.g.list_new();
+  s.g.list_add(list, s.sphere(v3(0, -1000, -1), 1000.0, s.lamb(0.8, 0.8, 0.8)));
+  for (int a = -11; a < 11; ++a) {
+    for (int b = -11; b < 11; ++b) {
+      if (std::abs(a - 0) <= 1 && std::abs(b - 0) <= 1) continue;
+      if (std::abs(a - 4) <= 1 && std::abs(b - 0) <= 1) continue;
+      double choose_mat = s.rnd();
+      double cx = (double)a + 0.9 * s.rnd();
+      double cy = 1.7 + s.rnd(0.0, 2.0);
+      double cz = (double)b + 0.9 * s.rnd();
+      Vec3 center = v3(cx, cy, cz);
+      if (rt::length(center - v3(4, 0.2, 0)) > 0.9) {
+        int32_t mat;
+        if (choose_mat < 0.3) {
+          Vec3 r1 = s.rnd3(); Vec3 r2 = s.rnd3();
+          mat = s.lamb(r1 * r2);
+        } else if (choose_mat < 0.6) {
+          Vec3 albedo = s.rnd3(0.5, 1.0);
+          double fuzz = s.rnd(0.0, 0.5);
+          mat = s.metal(albedo, fuzz);
+        } else {
+          mat = s.g.dielectric(1.5);
+        }
+        // world.rs:209-217: `if choose_mat < 1.0` -- always (gen::<f64>() < 1): every small sphere is a GravitySphere
+        double c[3] = {center.x, center.y, center.z};
+        s.g.list_add(list, s.g.gravity_sphere(c, 0.0, 0.2, mat));
+      }
+    }
+  }
+  s.g.list_add(list, s.sphere(v3(0, 1, 0), 1.0, s.g.dielectric(1.5)));
+  s.g.list_add(list, s.sphere(v3(-4, 1, 0), 1.0, s.lamb(0.4, 0.2, 0.1)));
+  s.g.list_add(list, s.sphere(v3(4, 1, 0), 1.0, s.metal(v3(0.7, 0.6, 0.5), 0.0)));
+  return s.g.bvh_from_list(list, 0.0, max_time);
 }
 
 // The Book-1 final scene as benchmarked in README.md:12-23 / images/book1.png: the loop
@@ -386,9 +425,10 @@ bool get_world_cam(SceneGraph& g, int32_t scene_id, const SceneOptions& opt, Wor
       world = gen_moving_test(s);
       aperture = 0.1; t1 = 2.0; t2 = 2.5;
       break;
-    case RTX_SCENE_RANDOM_MOVING:
-      *err = "scene 8 (gen_random_scene_moving / GravitySphere, world.rs:169-244) is the video experiment and is out of scope";
-      return false;
+    case RTX_SCENE_RANDOM_MOVING:                                              // world.rs:1051-1071
+      world = gen_random_scene_moving(s);
+      aperture = 0.1; t2 = 10.0;
+      break;
     case RTX_SCENE_BENCHMARK_TEST:                                             // world.rs:1072-1092
       world = benchmark_test_scene(s);
       aperture = 0.1; t2 = 10.0;

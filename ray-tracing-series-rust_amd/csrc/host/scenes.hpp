@@ -23,7 +23,7 @@ enum : int32_t {
   RTX_SCENE_CORNELL_SMOKE = 5,
   RTX_SCENE_BOOK2_FINAL = 6,
   RTX_SCENE_MOVING_TEST = 7,
-  RTX_SCENE_RANDOM_MOVING = 8,  // GravitySphere video scene: not on the hot path, unsupported
+  RTX_SCENE_RANDOM_MOVING = 8,  // gen_random_scene_moving: the GravitySphere video scene (world.rs:169-244)
   RTX_SCENE_BENCHMARK_TEST = 9,
   RTX_SCENE_TRIANGLE_TEST = 10,
   RTX_SCENE_STANFORD_DRAGON = 11,

@@ -85,9 +85,6 @@ def test_unsupported_shapes_are_reported_not_approximated(rtsr):
     with pytest.raises(rtsr.RtxError) as e:
         b.flatten(medium_in_bvh)
     assert e.value.status == rtsr.RTX_EUNSUPPORTED
-    with pytest.raises(rtsr.RtxError) as e:   # the GravitySphere video scene is out of scope
-        b.get_world_cam(rtsr.SCENE_RANDOM_MOVING)
-    assert e.value.status == rtsr.RTX_EUNSUPPORTED
 
 
 def test_missing_files(rtsr, tmp_path):
