@@ -1,0 +1,27 @@
+#!/bin/bash
+# All the evidence of a round for profiles/rNN (run on the GPU box through gpurun; writes gpurun_out/<out>/):
+#   scripts/profile_round2.sh <outdir-under-gpurun_out>
+#  bench_c2.json + bench_c2_pmc/   the headline bench line; its roofline comes from rocprofv3 --pmc child passes (raw CSVs kept)
+#  bench_c2_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (--no-pmc: profilers do not nest)
+#  bench_{head,c3_full,c4,c5_full}.json (+ _pmc/)   the other BASELINE configs at their full sizes, each with its counter passes
+#  classify_{a,b,c}.csv, issue_calib_w*.json, opcode_classes.json   per-opcode issue costs / counter classes (scripts/pmc_classify.sh)
+out=$1
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$out
+mkdir -p $O
+cd $R
+python3 bench.py --steps 20 --warmup 5 --keep-pmc $O/bench_c2_pmc > $O/bench_c2.json 2> $O/bench_c2.err || exit 1
+echo "[profile] c2 done"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-pmc --no-extras --no-cpu-baseline > $O/bench_c2_stats_run.json 2> $O/stats.err ) || exit 1
+cp $(ls $O/stats/*/*_kernel_stats.csv | head -1) $O/bench_c2_kernel_stats.csv && rm -rf $O/stats
+echo "[profile] stats done"
+python3 bench.py --workload head --steps 5 --warmup 1 --no-cpu-baseline --no-extras --keep-pmc $O/bench_head_pmc > $O/bench_head.json 2>> $O/bench.err || exit 1
+python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --keep-pmc $O/bench_c4_pmc > $O/bench_c4.json 2>> $O/bench.err || exit 1
+echo "[profile] head, c4 done"
+python3 bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-pmc > $O/bench_c3_full.json 2>> $O/bench.err || exit 1
+python3 bench.py --workload c3 --spp 256 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --keep-pmc $O/bench_c3_pmc > $O/bench_c3_256spp.json 2>> $O/bench.err || exit 1
+echo "[profile] c3 done"
+python3 bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-pmc --no-count > $O/bench_c5_full.json 2>> $O/bench.err || exit 1
+echo "[profile] c5 done"
+scripts/pmc_classify.sh $out || exit 1
+echo "[profile] classify done"
