@@ -16,9 +16,12 @@
  * Conventions: C99, no exceptions or aborts cross this boundary; every call that can fail
  * returns an rtx_status (or a negative handle) and leaves a message for rtx_last_error().
  * Plain pointers and sizes only.  Structs are POD, little-endian, 8-byte aligned.
- * Handles (rtx_handle) are indices owned by one builder.  A builder is single-threaded;
- * an rtx_flat / rtx_scene is immutable after creation and may be shared between threads;
- * render calls on one rtx_scene are serialised by the caller's stream.
+ * Handles (rtx_handle) are indices owned by one builder.  A builder is single-threaded.  An rtx_flat is immutable
+ * after creation and may be shared between threads.  An rtx_scene's GEOMETRY is immutable, but the handle also owns the
+ * render workspace (sample buffer, accumulators, work counter, timers): at most ONE render call may be in flight per
+ * rtx_scene at a time -- calls on one handle must come from one thread at a time and, for rtx_render_device, on one
+ * stream; concurrent renders of the same scene need one rtx_scene each (rtx_scene_upload is cheap next to a render).
+ * The workspace is kept until rtx_scene_destroy or rtx_scene_trim (default budget of the sample buffer: 6 GiB).
  */
 #ifndef RTX_ABI_H
 #define RTX_ABI_H
@@ -178,6 +181,8 @@ int32_t rtx_flat_top_level_kind(const rtx_flat* f, int32_t index);
 /* Copies every array to the CURRENT HIP device. */
 rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* s); /* NULL-safe */
+/* Releases the render workspace of an idle scene (it is re-allocated by the next render); the geometry stays resident. */
+rtx_status rtx_scene_trim(rtx_scene* s);
 
 /* ---- render: replaces render_scene's sample loop ------------------------------------------- */
 /* Pixel order everywhere: row-major, row j = 0 is the BOTTOM image row (Screen::update(j, i),

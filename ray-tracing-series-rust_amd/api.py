@@ -127,6 +127,7 @@ ABI = {
     "rtx_config_new": (C.c_int32, [C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RtxConfig)]),
     "rtx_image_height": (C.c_int32, [C.POINTER(RtxConfig)]),
     "rtx_flat_top_level_kind": (C.c_int32, [_VP, C.c_int32]),
+    "rtx_scene_trim": (C.c_int32, [_VP]),
     "rtx_multi_create": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_VP)]),
     "rtx_multi_destroy": (None, [_VP]),
     "rtx_multi_render": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.POINTER(RtxFrame), C.POINTER(RtxMultiStats)]),
@@ -415,6 +416,10 @@ class Scene:
                          rgb8.ctypes.data_as(C.POINTER(C.c_uint8)))
         _check(lib.rtx_render(self._p, C.byref(cam), C.byref(cfg), C.byref(frame)))
         return Screen(w, h, rgb8, accum)
+
+    def trim(self):
+        """Release the render workspace (sample buffer, accumulators); the geometry stays resident."""
+        _check(lib.rtx_scene_trim(self._p))
 
     def render_scene_with_time(self, t0, t1, path, row_chunk_compat=True, overrides=None):
         """render_scene_with_time(t0, t1, path, world) of world.rs:1249-1330 on this resident scene: one 500x500 PPM frame."""

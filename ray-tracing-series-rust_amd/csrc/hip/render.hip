@@ -793,6 +793,18 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
   return RTX_OK;
 }
 
+rtx_status rtx_scene_trim(rtx_scene* s) {
+  if (!s) { set_error("rtx_scene_trim: NULL scene"); return RTX_EINVAL; }
+  DeviceScene* ds = scene_device(s);
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != ds->device) { set_error("rtx_scene_trim: scene lives on a different device than the current one"); return RTX_EINVAL; }
+  HIP_TRY(hipDeviceSynchronize());
+  if (ds->samples) { HIP_TRY(hipFree(ds->samples)); ds->samples = nullptr; ds->samples_bytes = 0; }
+  if (ds->accum) { HIP_TRY(hipFree(ds->accum)); ds->accum = nullptr; ds->accum_bytes = 0; }
+  return RTX_OK;
+}
+
 void rtx_scene_destroy(rtx_scene* s) {
   if (!s) return;
   free_device_scene(scene_device(s));

@@ -103,6 +103,12 @@ struct MovingSphere {
     return {&s, checked(rtx_moving_sphere(s.builder(), a, b, t0, t1, radius, m.h))};
   }
 };
+struct GravitySphere {  // hit.rs:340-367
+  static Hittable new_(Scene& s, const Point3& start, double time0, double radius, Material m) {
+    double a[3] = {start.x, start.y, start.z};
+    return {&s, checked(rtx_gravity_sphere(s.builder(), a, time0, radius, m.h))};
+  }
+};
 struct Triangle {
   static Hittable new_(Scene& s, const Point3& v0, const Point3& v1, const Point3& v2, Material m) {
     double a[3] = {v0.x, v0.y, v0.z}, b[3] = {v1.x, v1.y, v1.z}, c[3] = {v2.x, v2.y, v2.z};
@@ -216,6 +222,43 @@ inline Screen render_scene(Scene& s, Hittable world, const Camera& cam, const Co
   rtx_scene_destroy(scene);
   check(st);
   return scr;
+}
+
+// render_scene on n GPUs of this process: row-interleaved shards, one RCCL gather (replaces the band threads and the
+// collect loop of world.rs:1198-1244 at node scale).
+inline Screen render_scene_multi(Scene& s, Hittable world, const Camera& cam, const Color& background, Config config, int n_gpus) {
+  config.c.background[0] = background.x; config.c.background[1] = background.y; config.c.background[2] = background.z;
+  rtx_flat* flat = nullptr;
+  check(rtx_flatten(s.builder(), world.h, nullptr, &flat));
+  Screen scr;
+  scr.width = config.c.image_width;
+  scr.height = rtx_image_height(&config.c);
+  scr.rgb8.resize((size_t)scr.width * scr.height * 3);
+  scr.accum.resize((size_t)scr.width * scr.height * 3);
+  RtxFrame frame = {scr.accum.data(), scr.rgb8.data()};
+  rtx_status st = rtx_render_multi(flat, &cam.c, &config.c, n_gpus, &frame);
+  rtx_flat_destroy(flat);
+  check(st);
+  return scr;
+}
+
+// render_scene_with_time(t0, t1, path, world) -- world.rs:1249-1330.  A ResidentWorld keeps the scene on the GPU across
+// frames (the reference's video loop rebuilt nothing either: it shares one Arc<world>).
+struct ResidentWorld {
+  rtx_scene* scene = nullptr;
+  ResidentWorld(Scene& s, Hittable world) {
+    rtx_flat* flat = nullptr;
+    check(rtx_flatten(s.builder(), world.h, nullptr, &flat));
+    rtx_status st = rtx_scene_upload(flat, &scene);
+    rtx_flat_destroy(flat);
+    check(st);
+  }
+  ~ResidentWorld() { rtx_scene_destroy(scene); }
+  ResidentWorld(const ResidentWorld&) = delete;
+  ResidentWorld& operator=(const ResidentWorld&) = delete;
+};
+inline void render_scene_with_time(double t0, double t1, const char* path, const ResidentWorld& world, bool row_chunk_compat = true) {
+  check(rtx_render_scene_with_time(world.scene, t0, t1, path, row_chunk_compat ? 1 : 0, nullptr));
 }
 
 }  // namespace rtsr
