@@ -73,6 +73,19 @@ RT_HD bool cull32_may_hit(const float* lo, const float* hi, const Ray32& q, floa
   return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));
 }
 
+// The same test with the near / far plane of every axis already picked by the sign of the ray's direction (near = lo
+// where the ray travels towards +axis, hi otherwise).  For a finite slope the near value IS min(a, b) and the far value
+// max(a, b) of cull32_may_hit, so tn / tf -- and the verdict -- are the same numbers; for a zero direction component
+// both are NaN and fmaxf / fminf drop them, exactly as there.  What it saves is the six min / max per box that only
+// sorted the two planes: on gfx950 v_min_f32 / v_max_f32 issue in 4 clocks, twice a v_fma_f32.
+RT_HD bool cull32_may_hit_nf(float nx, float fx, float ny, float fy, float nz, float fz, const Ray32& q, float t_max32) {
+  const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx, q.ix, -q.oix), __builtin_fmaf(ny, q.iy, -q.oiy)),
+                                                   __builtin_fmaf(nz, q.iz, -q.oiz)), q.t_min);
+  const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(fx, q.ix, -q.oix), __builtin_fmaf(fy, q.iy, -q.oiy)),
+                                                   __builtin_fmaf(fz, q.iz, -q.oiz)), t_max32);
+  return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));
+}
+
 // Both children of a node at once.  Same arithmetic as two cull32_may_hit calls; on the device the twelve plane
 // fmas are written as four 2-wide ones (x and y of a plane set) plus four scalar ones for z, so that the pairs
 // issue as v_pk_fma_f32 -- an fma gives the same value whichever instruction carries it.

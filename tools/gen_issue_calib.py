@@ -137,17 +137,34 @@ def main():
                 except ValueError:
                     pass
     ops = sorted(samples, key=lambda k: -counts[k])
+    # hand-written two-instruction bodies: what a compare + select costs through VCC and through an SGPR pair
+    EXTRA = {
+        "pair:v_cmp_lt_f32_e32(vcc)+v_cndmask_b32_e32(vcc)": ["v_cmp_lt_f32_e32 vcc, v96, v97", "v_cndmask_b32_e32 v{d}, v98, v99, vcc"],
+        "pair:v_cmp_lt_f32_e64(sgpr)+v_cndmask_b32_e64(sgpr)": ["v_cmp_lt_f32_e64 s[40:41], v96, v97", "v_cndmask_b32_e64 v{d}, v98, v99, s[40:41]"],
+        "pair:v_add_f32+v_cndmask_b32_e32(vcc)": ["v_add_f32_e32 v{d}, v96, v97", "v_cndmask_b32_e32 v{e}, v98, v99, vcc"],
+        "quad:3xv_fma_f32+v_cndmask_b32_e32(vcc)": ["v_fma_f32 v{d}, v96, v97, v98", "v_fma_f32 v{e}, v96, v97, v98", "v_fma_f32 v{d}, v96, v97, v99", "v_cndmask_b32_e32 v{e}, v98, v99, vcc"],
+    }
     with open(out_path, "w") as f:
         f.write("// GENERATED by tools/gen_issue_calib.py from the device assembly of the shipped kernels -- do not edit.\n")
         f.write("#include <hip/hip_runtime.h>\n")
         f.write("#define CLOB \"vcc\", \"scc\", \"memory\"" + "".join(', "v%d"' % r for r in range(64, 128)) + "".join(', "s%d"' % r for r in range(40, 60)) + "\n")
-        f.write("#define N_AUTO_OPS %d\n" % len(ops))
-        f.write("static const char* const AUTO_OP_NAMES[] = {%s};\n" % ", ".join('"%s"' % o for o in ops))
-        f.write("static const char* const AUTO_OP_SAMPLES[] = {%s};\n" % ", ".join('"%s"' % samples[o].replace('"', "'") for o in ops))
+        f.write("#define N_AUTO_OPS %d\n" % (len(ops) + len(EXTRA)))
+        f.write("static const char* const AUTO_OP_NAMES[] = {%s};\n" % ", ".join('"%s"' % o for o in list(ops) + list(EXTRA)))
+        f.write("static const char* const AUTO_OP_SAMPLES[] = {%s};\n" % ", ".join('"%s"' % x.replace('"', "'") for x in [samples[o] for o in ops] + [" ; ".join(b) for b in EXTRA.values()]))
         f.write("template <int OP> __device__ __forceinline__ void auto_body() {\n")
         for i, mn in enumerate(ops):
             lines = [rename(samples[mn], k % 8) for k in range(256)]
             f.write("  %sif constexpr (OP == %d) {\n" % ("" if i == 0 else "else ", i))
+            for c in range(0, 256, 32):
+                f.write('    asm volatile("' + "\\n".join(lines[c:c + 32]) + '" ::: CLOB);\n')
+            f.write("  }\n")
+        base = len(ops)
+        for j, (name, body) in enumerate(EXTRA.items()):
+            lines = []
+            for k in range(256 // len(body)):
+                for inst in body:
+                    lines.append(inst.format(d=64 + 4 * (k % 8), e=65 + 4 * (k % 8)))
+            f.write("  else if constexpr (OP == %d) {\n" % (base + j))
             for c in range(0, 256, 32):
                 f.write('    asm volatile("' + "\\n".join(lines[c:c + 32]) + '" ::: CLOB);\n')
             f.write("  }\n")
