@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W [--workload c2|c1|head|c3|c4|c5] [--spp S]
 
 A "step" is one full render of the workload: trace kernel(s) + ordered sample reduction + tone map,
-scene already resident in HBM.  At N=1 the workload is BASELINE.json configs[1] ("c2": Book-1 final
+scene already resident in HBM.  Steps are pipelined two deep (two resident copies of the scene, two streams), so that
+the tail of one frame overlaps the start of the next; the timed region covers K whole frames from first launch to last byte.  At N=1 the workload is BASELINE.json configs[1] ("c2": Book-1 final
 scene, 800x533, 500 spp, depth 50).  For N>1 the SAME image is sharded by rows over the ranks (one
 process per GPU, launched by torch.distributed.run) and the tone-mapped shards are gathered to rank 0
 with one RCCL gather per step: total work is fixed, so scaling is "strong".
@@ -336,51 +337,79 @@ def main():
     w = build_workload(rtsr, args.workload, args.spp, args.max_leaf, args.sah_bins)
     b, world, cam, cfg, flat = w["builder"], w["world"], w["cam"], w["cfg"], w["flat"]
     width, height, spp, depth, desc = w["width"], w["height"], w["spp"], w["depth"], w["desc"]
-    scene = flat.upload()
     n_cu = torch.cuda.get_device_properties(device_index).multi_processor_count
 
     shard = (rank, world_size, 1)  # rows j with j % N == rank
     my_rows = rtsr.shard_rows(cfg, shard)
     max_rows = max(rtsr.shard_rows(cfg, (r, world_size, 1)) for r in range(world_size))
-    d_rgb8 = torch.zeros(max_rows * width * 3, dtype=torch.uint8, device="cuda")
-    gather_list = None
-    host_stage = torch.empty(d_rgb8.numel(), dtype=torch.uint8) if (world_size > 1 and args.backend == "gloo") else None
+    # Frames are pipelined two deep: consecutive steps alternate between two resident copies of the scene (each owns its
+    # render workspace), two streams and two output buffers, so the tail of frame k -- its few 50-bounce paths in otherwise idle
+    # waves, the ordered reduction, the tone map and (N > 1) the gather -- overlaps the start of frame k + 1.  Nothing is skipped:
+    # every step still traces, reduces, tone-maps and gathers one full frame; the timed region ends when all of them have finished.
+    N_PIPE = 2
+    scenes = [flat.upload() for _ in range(N_PIPE)]
+    scene = scenes[0]
+    streams = [torch.cuda.Stream() for _ in range(N_PIPE)]
+    bufs = [torch.zeros(max_rows * width * 3, dtype=torch.uint8, device="cuda") for _ in range(N_PIPE)]
+    d_rgb8 = bufs[0]
+    use_gloo = world_size > 1 and args.backend == "gloo"
+    host_stage = [torch.empty(bufs[0].numel(), dtype=torch.uint8) for _ in range(N_PIPE)] if use_gloo else None
+    gather_lists = [None] * N_PIPE
     if world_size > 1 and rank == 0:
-        gather_list = [torch.empty_like(host_stage if host_stage is not None else d_rgb8) for _ in range(world_size)]
-    stream = torch.cuda.current_stream().cuda_stream
+        gather_lists = [[torch.empty_like(host_stage[0] if use_gloo else bufs[0]) for _ in range(world_size)] for _ in range(N_PIPE)]
+    pending = [None] * N_PIPE
+    step_no = [0]
 
-    trace_ms = []
-    kernel_used = []
-
-    def step(record):
-        stats = scene.render_device(cam, cfg, shard=shard, d_rgb8=d_rgb8.data_ptr(), stream=stream, want_stats=True)
-        if record:
-            trace_ms.append((stats.trace_ms, stats.trace_launches))
-            kernel_used.append(stats.trace_kernel)
-        if world_size > 1:
-            if host_stage is not None:
-                host_stage.copy_(d_rgb8)  # gloo rehearsal path only
-                dist.gather(host_stage, gather_list=gather_list, dst=0)
-            else:
-                dist.gather(d_rgb8, gather_list=gather_list, dst=0)  # one RCCL gather per frame
+    def step():
+        p = step_no[0] % N_PIPE
+        step_no[0] += 1
+        with torch.cuda.stream(streams[p]):
+            if pending[p] is not None:
+                pending[p].wait()  # the gather that last read this buffer (stream-side wait, the host goes on)
+                pending[p] = None
+            scenes[p].render_device(cam, cfg, shard=shard, d_rgb8=bufs[p].data_ptr(), stream=streams[p].cuda_stream)
+            if world_size > 1:
+                if use_gloo:
+                    host_stage[p].copy_(bufs[p])  # gloo rehearsal path only (synchronises)
+                    dist.gather(host_stage[p], gather_list=gather_lists[p], dst=0)
+                else:
+                    pending[p] = dist.gather(bufs[p], gather_list=gather_lists[p], dst=0, async_op=True)  # one RCCL gather per frame
 
     def fence():
+        for p in range(N_PIPE):
+            if pending[p] is not None:
+                with torch.cuda.stream(streams[p]):
+                    pending[p].wait()
+                pending[p] = None
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step()
     fence()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    last = (step_no[0] - 1) % N_PIPE
+    d_rgb8 = bufs[last]
+    gather_list = gather_lists[last]
+    # the trace kernel's own duration: HIP events around its launches on the launch stream, in three untimed frames of the same
+    # shard run one at a time (inside the pipelined region the events of two streams would interleave)
+    trace_ms = []
+    kernel_used = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        stats = scene.render_device(cam, cfg, shard=shard, d_rgb8=bufs[0].data_ptr(), stream=stream, want_stats=True)
+        trace_ms.append((stats.trace_ms, stats.trace_launches))
+        kernel_used.append(stats.trace_kernel)
+    torch.cuda.synchronize()
 
     total_samples = float(width) * height * spp  # whole job, all ranks
     value = total_samples * args.steps / elapsed / 1e6
@@ -443,7 +472,7 @@ def main():
             counts = {k: getattr(st, k) for k in ("box_tests", "sphere_tests", "moving_sphere_tests", "rect_tests",
                                                   "triangle_tests", "scatters", "texels", "perlin_calls", "rays", "samples")}
             bytes_per_sample = algorithmic_bytes(counts) / float(counts["samples"])
-            samples_per_launch = float(my_rows) * width * spp / max(1, launches // max(1, args.steps))
+            samples_per_launch = float(my_rows) * width * spp / max(1, launches // max(1, len(trace_ms)))
             achieved = bytes_per_sample * samples_per_launch / (mean_trace_ms * 1e-3) / 1e9
             roofline["algorithmic"] = {"bytes_per_sample": round(bytes_per_sample, 1), "achieved": round(achieved, 1), "unit": "GB/s",
                                        "over_hbm_peak": round(achieved / HBM_PEAK_GBS, 3),
@@ -455,7 +484,8 @@ def main():
         extras = None
         if world_size == 1 and not args.no_extras and args.workload == "c2" and args.spp == 0:
             extras = {}
-            del scene  # free C2's sample buffer first
+            scenes.clear()
+            del scene  # free C2's sample buffers first
             torch.cuda.empty_cache()
             for name, x_spp, x_steps in (("head", 0, 3), ("c3", 256, 2), ("c4", 0, 2), ("c5", 120, 1)):
                 try:
@@ -515,7 +545,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": round(value / 1.4559, 1), "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "width": width, "height": height, "spp": spp, "max_depth": depth,
-                       "scene_seed": 1, "render_seed": 1, "flatten_s": round(w["flatten_s"], 3), "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
+                       "scene_seed": 1, "render_seed": 1, "flatten_s": round(w["flatten_s"], 3), "frames_in_flight": N_PIPE, "sharding": "rows j %% %d == rank, one RCCL gather of RGB8 per step" % world_size
                        if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_cpu_published": {"value": 1.4559, "unit": "Msamples/s", "source": "README.md:23, 10 threads, CPU unstated"},
