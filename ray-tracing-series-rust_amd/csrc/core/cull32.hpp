@@ -35,11 +35,11 @@ struct Ray32 {
   float t_min;          // rounded down
 };
 
-RT_HD float cull_round_up(double x) {  // an f32 >= x (inf stays inf)
+RT_HD float cull_round_up(real x) {  // an f32 >= x (inf stays inf)
   return (float)x * (x >= 0.0 ? 1.00000012f : 0.99999988f);
 }
 
-RT_HD Ray32 make_ray32(const Ray& r, double t_min) {
+RT_HD Ray32 make_ray32(const Ray& r, real t_min) {
   Ray32 q;
   float ox = (float)r.origin.x, oy = (float)r.origin.y, oz = (float)r.origin.z;
 #if defined(__HIP_DEVICE_COMPILE__)

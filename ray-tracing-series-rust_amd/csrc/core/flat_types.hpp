@@ -27,13 +27,13 @@ RT_HD uint32_t primref_type(PrimRef r) { return r >> 29; }
 RT_HD uint32_t primref_index(PrimRef r) { return r & 0x1fffffffu; }
 
 struct FlatSphere {  // 40 B
-  double cx, cy, cz, radius;
+  real cx, cy, cz, radius;
   int32_t mat;
   int32_t pad;
 };
 struct FlatMovingSphere {  // 80 B
-  double c0[3], c1[3];
-  double time0, time1, radius;
+  real c0[3], c1[3];
+  real time0, time1, radius;
   int32_t mat;
   int32_t pad;
 };
@@ -41,8 +41,8 @@ struct FlatMovingSphere {  // 80 B
 // 0.001 and stores every height: ~100 002 doubles per ball); times past the table fall back to the reference's second,
 // slightly different simulation loop (hit.rs:378-389).
 struct FlatGravitySphere {  // 64 B
-  double sx, sy, sz;   // start
-  double time0, radius;
+  real sx, sy, sz;   // start
+  real time0, radius;
   int32_t mat;
   int32_t pad;
   int64_t table_first; // index into SceneView::gravity_y
@@ -50,12 +50,12 @@ struct FlatGravitySphere {  // 64 B
 };
 enum RectAxis : int32_t { RECT_XY = 0, RECT_XZ = 1, RECT_YZ = 2 };
 struct FlatRect {  // 48 B.  (a0,a1,b0,b1,k) are the constructor's (x0,x1,y0,y1,k).
-  double a0, a1, b0, b1, k;
+  real a0, a1, b0, b1, k;
   int32_t axis;
   int32_t mat;
 };
 struct FlatTriangle {  // 104 B
-  double v0[3], v1[3], v2[3], normal[3];  // normal = unit((v1-v0) x (v2-v0)), hit.rs:96-107
+  real v0[3], v1[3], v2[3], normal[3];  // normal = unit((v1-v0) x (v2-v0)), hit.rs:96-107
   int32_t mat;
   int32_t pad;
 };
@@ -66,8 +66,8 @@ struct FlatTriangle {  // 104 B
 // bits 3..30 = first slot in the BVH's primitive-reference list (relative to
 // FlatBvh.first_ref).  Leaves hold 1..8 primitives.
 struct FlatNode {  // 112 B
-  double bmin[2][3];
-  double bmax[2][3];
+  real bmin[2][3];
+  real bmax[2][3];
   int32_t child[2];
   int32_t pad[2];
 };
@@ -101,12 +101,12 @@ enum XformOp : int32_t { XFORM_TRANSLATE = 0, XFORM_ROTATE_Y = 1 };
 struct FlatXformOp {
   int32_t op;
   int32_t pad;
-  double v[3];  // translate: offset; rotate_y: v[0] = sin_theta, v[1] = cos_theta
+  real v[3];  // translate: offset; rotate_y: v[0] = sin_theta, v[1] = cos_theta
 };
 struct FlatEntry {
   int32_t kind;
   int32_t a, b, c;
-  double f[2];
+  real f[2];
   FlatXformOp ops[RT_MAX_XFORM_OPS];
 };
 
@@ -121,8 +121,8 @@ enum MaterialKind : int32_t {
 struct FlatMaterial {  // 48 B
   int32_t kind;
   int32_t tex;       // albedo / emit texture (Lambertian, DiffuseLight, Isotropic)
-  double albedo[3];  // Metal
-  double param;      // Metal: fuzz (already clamped to <= 1); Dielectric: ir
+  real albedo[3];  // Metal
+  real param;      // Metal: fuzz (already clamped to <= 1); Dielectric: ir
   int32_t needs_uv;  // 1 if the texture tree below `tex` contains an Image texture
   int32_t pad;
 };
@@ -136,11 +136,11 @@ struct FlatTexture {  // 48 B
   int32_t kind;
   int32_t a, b;
   int32_t pad;
-  double color[3];
-  double scale;
+  real color[3];
+  real scale;
 };
 struct FlatPerlin {  // 9216 B, perlin.rs:6-11
-  double ranvec[256][3];
+  real ranvec[256][3];
   int32_t perm_x[256], perm_y[256], perm_z[256];
 };
 struct FlatImage {  // texels are f64 triples exactly as Screen::from_ppm_p3 parses them
@@ -151,7 +151,7 @@ struct FlatImage {  // texels are f64 triples exactly as Screen::from_ppm_p3 par
 // camera.rs:6-17
 struct FlatCamera {  // 192 B
   Vec3 origin, lower_left_corner, horizontal, vertical, u, v, w;
-  double lens_radius, time1, time2;
+  real lens_radius, time1, time2;
 };
 
 // ---- a view over one flattened scene (pointers into host memory, HBM or LDS) ---
@@ -169,13 +169,13 @@ struct SceneView {
   const FlatTexture* textures;
   const FlatPerlin* perlins;
   const FlatImage* images;
-  const double* texels;  // 3 doubles per texel
+  const real* texels;  // 3 doubles per texel
   // f32 bounding box (lo xyz, hi xyz; rounded outward) of every top-level slot that is a plain static primitive,
   // (-inf, +inf) for every other slot: lets the list scan skip a primitive test no lane of the wave can pass
   // (core/cull32.hpp: conservative, cannot change a result).  May be null.
   const float* top_box32;
   const FlatGravitySphere* gravity_spheres;
-  const double* gravity_y;  // the height tables of all gravity spheres, one after another
+  const real* gravity_y;  // the height tables of all gravity spheres, one after another
   int32_t n_top_level;
   int32_t max_stack;  // deepest traversal stack any BVH of this scene needs
   uint32_t features;  // Feature bits the scene can reach

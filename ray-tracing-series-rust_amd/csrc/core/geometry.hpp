@@ -28,30 +28,30 @@ namespace rt {
 struct HitRecord {
   Point3 p;
   Vec3 normal;
-  double t, u, v;
+  real t, u, v;
   bool front_face;
   int32_t mat;
 };
 
 // hit.rs:69-79
 RT_HD void create_normal_face(const Ray& r, Vec3 outward_normal, Vec3* normal, bool* front_face) {
-  bool ff = dot(r.direction, outward_normal) < 0.0;
+  bool ff = dot(r.direction, outward_normal) < real(0.0);
   *normal = ff ? outward_normal : -outward_normal;
   *front_face = ff;
 }
 
 // hit.rs:195-200.  Out of line: only Image-textured spheres use uv, and acos/atan2 are long.
-RT_HD void get_sphere_uv(Point3 p, double* u, double* v) {
-  double theta = rt_acos(-p.y);
-  double phi = rt_atan2(-p.z, p.x) + RT_PI;
-  *u = phi / (2.0 * RT_PI);
+RT_HD void get_sphere_uv(Point3 p, real* u, real* v) {
+  real theta = rt_acos(-p.y);
+  real phi = rt_atan2(-p.z, p.x) + RT_PI;
+  *u = phi / (real(2.0) * RT_PI);
   *v = theta / RT_PI;
 }
 
-RT_HD Vec3 load_v3(const double* p) { return v3(p[0], p[1], p[2]); }
+RT_HD Vec3 load_v3(const real* p) { return v3(p[0], p[1], p[2]); }
 
 // hit.rs:275-278
-RT_HD Point3 moving_sphere_center(const FlatMovingSphere& s, double time) {
+RT_HD Point3 moving_sphere_center(const FlatMovingSphere& s, real time) {
   Point3 c0 = load_v3(s.c0), c1 = load_v3(s.c1);
   return c0 + ((time - s.time0) / (s.time1 - s.time0)) * (c1 - c0);
 }
@@ -59,35 +59,35 @@ RT_HD Point3 moving_sphere_center(const FlatMovingSphere& s, double time) {
 // GravitySphere::get_center (hit.rs:369-391), literally: the table when `(time / incr) as usize + 1 <= stored.len()`
 // (a saturating cast: negative or NaN times index entry 0), otherwise the brute-force loop with its own constants
 // (2 x radius, restitution 0.8 -- the reference's "radius x2 bug" comment).
-RT_HD Point3 gravity_sphere_center(const FlatGravitySphere& s, const double* table, double time) {
-  const double incr = 0.001;
-  const double q = time / incr;
+RT_HD Point3 gravity_sphere_center(const FlatGravitySphere& s, const real* table, real time) {
+  const real incr = real(0.001);
+  const real q = time / incr;
   uint64_t idx;  // Rust `as usize`: saturating, NaN -> 0
-  if (!(q == q) || q <= 0.0) idx = 0;
-  else if (q >= 18446744073709551615.0) idx = ~0ull;
+  if (!(q == q) || q <= real(0.0)) idx = 0;
+  else if (q >= real(18446744073709551615.0)) idx = ~0ull;
   else idx = (uint64_t)q;
   if (idx < ~0ull && idx + 1 <= (uint64_t)s.table_len) return v3(s.sx, table[s.table_first + (int64_t)idx], s.sz);
-  double t = s.time0, y = s.sy, vel = 0.0;
+  real t = s.time0, y = s.sy, vel = real(0.0);
   while (t < time) {
     t += incr;
-    vel -= 0.000001;
-    if (y - 2.0 * s.radius <= 0.0) vel *= -0.8;
-    y = rt_fmax(2.0 * s.radius, y + vel);
+    vel -= real(0.000001);
+    if (y - real(2.0) * s.radius <= real(0.0)) vel *= -real(0.8);
+    y = rt_fmax(real(2.0) * s.radius, y + vel);
   }
   return v3(s.sx, y, s.sz);
 }
 
 // Shared by Sphere::hit (hit.rs:204-222) and MovingSphere::hit (hit.rs:282-300).
-RT_HD bool sphere_root(Point3 center, double radius, const Ray& r, double t_min, double t_max,
-                       double* t_out) {
+RT_HD bool sphere_root(Point3 center, real radius, const Ray& r, real t_min, real t_max,
+                       real* t_out) {
   Vec3 oc = r.origin - center;
-  double a = length_squared(r.direction);
-  double half_b = dot(oc, r.direction);
-  double c = length_squared(oc) - radius * radius;
-  double discriminant = half_b * half_b - a * c;
-  if (discriminant < 0.0) return false;
-  double sqrtd = rt_sqrt(discriminant);
-  double root = (-half_b - sqrtd) / a;
+  real a = length_squared(r.direction);
+  real half_b = dot(oc, r.direction);
+  real c = length_squared(oc) - radius * radius;
+  real discriminant = half_b * half_b - a * c;
+  if (discriminant < real(0.0)) return false;
+  real sqrtd = rt_sqrt(discriminant);
+  real root = (-half_b - sqrtd) / a;
   if (root < t_min || t_max < root) {
     root = (-half_b + sqrtd) / a;
     if (root < t_min || t_max < root) return false;
@@ -97,38 +97,38 @@ RT_HD bool sphere_root(Point3 center, double radius, const Ray& r, double t_min,
 }
 
 // hit.rs:111-149: plane hit, range test, three inside-edge tests.
-RT_HD bool triangle_t(const FlatTriangle& tr, const Ray& r, double t_min, double t_max,
-                      double* t_out) {
+RT_HD bool triangle_t(const FlatTriangle& tr, const Ray& r, real t_min, real t_max,
+                      real* t_out) {
   Vec3 n = load_v3(tr.normal), v0 = load_v3(tr.v0), v1 = load_v3(tr.v1), v2 = load_v3(tr.v2);
-  double n_dot_d = dot(n, r.direction);
-  if (rt_fabs(n_dot_d) < 0.0001) return false;
-  double d = -dot(n, v0);
-  double t = -(dot(n, r.origin) + d) / n_dot_d;
+  real n_dot_d = dot(n, r.direction);
+  if (rt_fabs(n_dot_d) < real(0.0001)) return false;
+  real d = -dot(n, v0);
+  real t = -(dot(n, r.origin) + d) / n_dot_d;
   if (t < t_min || t > t_max) return false;
   Point3 p = ray_at(r, t);
   Vec3 c = cross(v1 - v0, p - v0);
-  if (dot(n, c) < 0.0) return false;
+  if (dot(n, c) < real(0.0)) return false;
   c = cross(v2 - v1, p - v1);
-  if (dot(n, c) < 0.0) return false;
+  if (dot(n, c) < real(0.0)) return false;
   c = cross(v0 - v2, p - v2);
-  if (dot(n, c) < 0.0) return false;
+  if (dot(n, c) < real(0.0)) return false;
   *t_out = t;
   return true;
 }
 
 // hit.rs:476-485 (Xy), 541-550 (Xz), 606-615 (Yz).  One body per axis, each naming the ray
 // components it reads (a runtime-selected member turns into an indexed stack load on the GPU).
-RT_HD bool rect_core(const FlatRect& q, double ok, double dk, double oa, double da, double ob, double db,
-                     double t_min, double t_max, double* t_out) {
-  double t = (q.k - ok) / dk;
+RT_HD bool rect_core(const FlatRect& q, real ok, real dk, real oa, real da, real ob, real db,
+                     real t_min, real t_max, real* t_out) {
+  real t = (q.k - ok) / dk;
   if (t < t_min || t > t_max) return false;
-  double x = oa + t * da;
-  double y = ob + t * db;
+  real x = oa + t * da;
+  real y = ob + t * db;
   if (x < q.a0 || x > q.a1 || y < q.b0 || y > q.b1) return false;
   *t_out = t;
   return true;
 }
-RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, double* t_out) {
+RT_HD bool rect_t(const FlatRect& q, const Ray& r, real t_min, real t_max, real* t_out) {
   if (q.axis == RECT_XY)
     return rect_core(q, r.origin.z, r.direction.z, r.origin.x, r.direction.x, r.origin.y, r.direction.y, t_min, t_max, t_out);
   if (q.axis == RECT_XZ)
@@ -137,8 +137,8 @@ RT_HD bool rect_t(const FlatRect& q, const Ray& r, double t_min, double t_max, d
 }
 
 template <uint32_t F, bool COUNT>
-RT_HD bool prim_t(const SceneView& sv, PrimRef ref, const Ray& r, double t_min, double t_max,
-                  double* t_out, TraceCounters* cnt) {
+RT_HD bool prim_t(const SceneView& sv, PrimRef ref, const Ray& r, real t_min, real t_max,
+                  real* t_out, TraceCounters* cnt) {
   uint32_t idx = primref_index(ref);
   uint32_t type = primref_type(ref);
   if ((F & F_SPHERE) && (type == PRIM_SPHERE || !(F & (F_MOVING_SPHERE | F_RECT | F_TRIANGLE | F_GRAVITY_SPHERE)))) {
@@ -169,7 +169,7 @@ RT_HD bool prim_t(const SceneView& sv, PrimRef ref, const Ray& r, double t_min, 
 
 // Build the HitRecord of the winning primitive (the tail of each Hittable::hit).
 template <uint32_t F>
-RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double t, HitRecord* rec) {
+RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, real t, HitRecord* rec) {
   uint32_t idx = primref_index(ref);
   uint32_t type = primref_type(ref);
   rec->t = t;
@@ -180,7 +180,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     Vec3 outward = (rec->p - v3(s.cx, s.cy, s.cz)) / s.radius;
     create_normal_face(r, outward, &rec->normal, &rec->front_face);
     rec->mat = s.mat;
-    rec->u = 0.0; rec->v = 0.0;  // only read by Image textures
+    rec->u = real(0.0); rec->v = real(0.0);  // only read by Image textures
     if (F & F_IMAGE) {
       if (sv.materials[s.mat].needs_uv) get_sphere_uv(outward, &rec->u, &rec->v);
     }
@@ -192,13 +192,13 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     Vec3 outward = (rec->p - moving_sphere_center(s, r.time)) / s.radius;
     create_normal_face(r, outward, &rec->normal, &rec->front_face);
     rec->mat = s.mat;
-    rec->u = 0.0; rec->v = 0.0;
+    rec->u = real(0.0); rec->v = real(0.0);
     return;
   }
   if ((F & F_RECT) && (type == PRIM_RECT || !(F & (F_TRIANGLE | F_GRAVITY_SPHERE)))) {
     // hit.rs:486-500, 551-565, 616-630
     const FlatRect& q = sv.rects[idx];
-    rec->u = 0.0; rec->v = 0.0;
+    rec->u = real(0.0); rec->v = real(0.0);
     if (q.axis == RECT_XY) {
       if ((F & F_IMAGE) && sv.materials[q.mat].needs_uv) {
         rec->u = ((r.origin.x + t * r.direction.x) - q.a0) / (q.a1 - q.a0);
@@ -226,7 +226,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     const FlatTriangle& tr = sv.triangles[idx];
     create_normal_face(r, load_v3(tr.normal), &rec->normal, &rec->front_face);
     rec->mat = tr.mat;
-    rec->u = 1.0; rec->v = 1.0;
+    rec->u = real(1.0); rec->v = real(1.0);
     return;
   }
   if (F & F_GRAVITY_SPHERE) {
@@ -235,7 +235,7 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
     Vec3 outward = (rec->p - gravity_sphere_center(s, sv.gravity_y, r.time)) / s.radius;
     create_normal_face(r, outward, &rec->normal, &rec->front_face);
     rec->mat = s.mat;
-    rec->u = 0.0; rec->v = 0.0;
+    rec->u = real(0.0); rec->v = real(0.0);
   }
 }
 
@@ -255,38 +255,38 @@ RT_HD void prim_finalize(const SceneView& sv, PrimRef ref, const Ray& r, double 
 // topology luck, Q7).  With "may hit" the closest hit is the closest primitive hit, independent of tree
 // shape and of which walker (f64 or f32 culling) runs.  tests/test_oracle_pairs.py::test_axis_aligned_triangles.
 template <bool STRICT>
-RT_HD bool aabb_interval(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min,
-                         double t_max) {
+RT_HD bool aabb_interval(const real* bmin, const real* bmax, Point3 o, Vec3 inv_d, real t_min,
+                         real t_max) {
   {
-    double t0 = (bmin[0] - o.x) * inv_d.x, t1 = (bmax[0] - o.x) * inv_d.x;
-    if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    real t0 = (bmin[0] - o.x) * inv_d.x, t1 = (bmax[0] - o.x) * inv_d.x;
+    if (inv_d.x < real(0.0)) { real s = t0; t0 = t1; t1 = s; }
     t_min = t0 > t_min ? t0 : t_min;
     t_max = t1 < t_max ? t1 : t_max;
   }
   {
-    double t0 = (bmin[1] - o.y) * inv_d.y, t1 = (bmax[1] - o.y) * inv_d.y;
-    if (inv_d.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    real t0 = (bmin[1] - o.y) * inv_d.y, t1 = (bmax[1] - o.y) * inv_d.y;
+    if (inv_d.y < real(0.0)) { real s = t0; t0 = t1; t1 = s; }
     t_min = t0 > t_min ? t0 : t_min;
     t_max = t1 < t_max ? t1 : t_max;
   }
   {
-    double t0 = (bmin[2] - o.z) * inv_d.z, t1 = (bmax[2] - o.z) * inv_d.z;
-    if (inv_d.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    real t0 = (bmin[2] - o.z) * inv_d.z, t1 = (bmax[2] - o.z) * inv_d.z;
+    if (inv_d.z < real(0.0)) { real s = t0; t0 = t1; t1 = s; }
     t_min = t0 > t_min ? t0 : t_min;
     t_max = t1 < t_max ? t1 : t_max;
   }
   return STRICT ? !(t_max <= t_min) : !(t_max < t_min);
 }
-RT_HD bool aabb_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min, double t_max) {
+RT_HD bool aabb_hit(const real* bmin, const real* bmax, Point3 o, Vec3 inv_d, real t_min, real t_max) {
   return aabb_interval<true>(bmin, bmax, o, inv_d, t_min, t_max);
 }
-RT_HD bool aabb_may_hit(const double* bmin, const double* bmax, Point3 o, Vec3 inv_d, double t_min, double t_max) {
+RT_HD bool aabb_may_hit(const real* bmin, const real* bmax, Point3 o, Vec3 inv_d, real t_min, real t_max) {
   return aabb_interval<false>(bmin, bmax, o, inv_d, t_min, t_max);
 }
 
 // A traversal's running answer.
 struct Closest {
-  double t;
+  real t;
   PrimRef ref;
   uint32_t order;  // slot in the owning list (tie break)
   bool hit;
@@ -296,9 +296,9 @@ struct Closest {
 // reference's (strict on both ends, so t == closest is accepted); `order`
 // makes the tie outcome independent of the visiting order.
 template <uint32_t F, bool COUNT>
-RT_HD void offer_prim(const SceneView& sv, PrimRef ref, uint32_t order, const Ray& r, double t_min,
+RT_HD void offer_prim(const SceneView& sv, PrimRef ref, uint32_t order, const Ray& r, real t_min,
                       Closest* best, TraceCounters* cnt) {
-  double t;
+  real t;
   if (!prim_t<F, COUNT>(sv, ref, r, t_min, best->t, &t, cnt)) return;
   if (best->hit && t == best->t && order < best->order) return;
   best->t = t;
@@ -315,7 +315,7 @@ RT_HD void offer_prim(const SceneView& sv, PrimRef ref, uint32_t order, const Ra
 // of many rays per lane (hip/render.hip, k_trace_stream); bvh_closest below simply loops it.
 template <uint32_t F, bool COUNT, class STACK>
 RT_HD bool bvh_step(const SceneView& sv, uint32_t first_ref, const Ray& r, Vec3 inv_d, uint32_t dir_neg,
-                    double t_min, int32_t* node, Closest* best, STACK& stack, TraceCounters* cnt) {
+                    real t_min, int32_t* node, Closest* best, STACK& stack, TraceCounters* cnt) {
   const FlatNode& n = sv.nodes[*node];
   if (COUNT) cnt->box_tests += 2;
   int first = (int)((dir_neg >> (uint32_t)n.pad[0]) & 1u);  // near child along the split axis
@@ -353,15 +353,15 @@ RT_HD bool bvh_step(const SceneView& sv, uint32_t first_ref, const Ray& r, Vec3 
 }
 
 RT_HD Vec3 ray_inv_dir(const Ray& r) {  // aabb.rs:48: inv_d = 1.0 / direction, per axis
-  return v3(1.0 / r.direction.x, 1.0 / r.direction.y, 1.0 / r.direction.z);
+  return v3(real(1.0) / r.direction.x, real(1.0) / r.direction.y, real(1.0) / r.direction.z);
 }
 RT_HD uint32_t ray_dir_neg(const Ray& r) {  // bit a set: the ray travels towards -a
-  return (r.direction.x < 0.0 ? 1u : 0u) | (r.direction.y < 0.0 ? 2u : 0u) | (r.direction.z < 0.0 ? 4u : 0u);
+  return (r.direction.x < real(0.0) ? 1u : 0u) | (r.direction.y < real(0.0) ? 2u : 0u) | (r.direction.z < real(0.0) ? 4u : 0u);
 }
 
 template <uint32_t F, bool COUNT, class STACK>
 RT_HD void bvh_closest(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r,
-                       double t_min, Closest* best, STACK& stack, TraceCounters* cnt) {
+                       real t_min, Closest* best, STACK& stack, TraceCounters* cnt) {
   Vec3 inv_d = ray_inv_dir(r);
   uint32_t dir_neg = ray_dir_neg(r);
   stack.reset();
@@ -375,7 +375,7 @@ RT_HD void bvh_closest(const SceneView& sv, int32_t root, uint32_t first_ref, co
 // closest hit under offer_prim's rule, so the choice is invisible in results.
 struct SerialWalk {
   template <uint32_t F, bool COUNT, class STACK>
-  RT_HD static void run(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r, double t_min,
+  RT_HD static void run(const SceneView& sv, int32_t root, uint32_t first_ref, const Ray& r, real t_min,
                         Closest* best, STACK& stack, TraceCounters* cnt) {
     bvh_closest<F, COUNT>(sv, root, first_ref, r, t_min, best, stack, cnt);
   }
@@ -383,8 +383,8 @@ struct SerialWalk {
 
 // PRIM / GROUP / BVH entries: find the closest candidate in [t_min, t_max].
 template <uint32_t F, bool COUNT, class STACK, class WALK = SerialWalk>
-RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, double t_min,
-                        double t_max, Closest* best, STACK& stack, TraceCounters* cnt) {
+RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, real t_min,
+                        real t_max, Closest* best, STACK& stack, TraceCounters* cnt) {
   best->t = t_max;
   best->hit = false;
   best->ref = 0;
@@ -394,7 +394,7 @@ RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, d
     return;
   }
   if ((F & F_PRIM_ENTRY) && (e.kind == ENTRY_PRIM || !(F & F_GROUP))) {
-    double t;
+    real t;
     if (prim_t<F, COUNT>(sv, (PrimRef)e.a, r, t_min, t_max, &t, cnt)) {
       best->t = t; best->ref = (PrimRef)e.a; best->hit = true;
     }
@@ -404,7 +404,7 @@ RT_HD void geom_closest(const SceneView& sv, const FlatEntry& e, const Ray& r, d
     // HittableList::hit (hit.rs:660-690): in order, shrinking closest_so_far, later wins ties.
     for (int32_t i = 0; i < e.b; ++i) {
       PrimRef ref = sv.refs[e.a + i];
-      double t;
+      real t;
       if (prim_t<F, COUNT>(sv, ref, r, t_min, best->t, &t, cnt)) {
         best->t = t; best->ref = ref; best->order = (uint32_t)i; best->hit = true;
       }
@@ -417,7 +417,7 @@ RT_HD Ray xform_ray(const FlatXformOp& op, const Ray& r) {
   if (op.op == XFORM_TRANSLATE) {
     return make_ray(r.origin - load_v3(op.v), r.direction, r.time);
   }
-  double sin_t = op.v[0], cos_t = op.v[1];
+  real sin_t = op.v[0], cos_t = op.v[1];
   Vec3 o = v3(cos_t * r.origin.x - sin_t * r.origin.z, r.origin.y,
               sin_t * r.origin.x + cos_t * r.origin.z);
   Vec3 d = v3(cos_t * r.direction.x - sin_t * r.direction.z, r.direction.y,
@@ -435,7 +435,7 @@ RT_HD void xform_record(const FlatXformOp& op, const Ray& child_ray, HitRecord* 
     rec->p = rec->p + load_v3(op.v);
     return;
   }
-  double sin_t = op.v[0], cos_t = op.v[1];
+  real sin_t = op.v[0], cos_t = op.v[1];
   Vec3 p = v3(cos_t * rec->p.x + sin_t * rec->p.z, rec->p.y, -sin_t * rec->p.x + cos_t * rec->p.z);
   Vec3 n = v3(cos_t * rec->normal.x + sin_t * rec->normal.z, rec->normal.y,
               -sin_t * rec->normal.x + cos_t * rec->normal.z);
@@ -451,11 +451,11 @@ RT_HD void xform_record(const FlatXformOp& op, const Ray& child_ray, HitRecord* 
 // then draws one uniform from the path's stream -- inside the intersection, exactly where
 // the reference draws it (hit.rs:969).
 template <uint32_t F, bool COUNT, class STACK, class WALK = SerialWalk>
-RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_max, HitRecord* rec,
+RT_HD bool world_hit(const SceneView& sv, const Ray& r, real t_min, real t_max, HitRecord* rec,
                      Rng& rng, STACK& stack, TraceCounters* cnt) {
   if (COUNT) cnt->rays++;
   bool hit_anything = false;
-  double closest_so_far = t_max;
+  real closest_so_far = t_max;
   // plain primitives in the list: a conservative f32 box test per lane, and the f64 primitive test is skipped when
   // no lane of the wave can pass it (most waves never see Book-2's small spheres)
   const bool cull_prims = (F & F_PRIM_ENTRY) && sv.top_box32 != nullptr;
@@ -490,36 +490,36 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, double t_min, double t_m
     }
 
     Closest best;
-    double q_min = is_medium ? -RT_INFINITY : t_min;
-    double q_max = is_medium ? RT_INFINITY : closest_so_far;
-    double rec1_t = 0.0;
+    real q_min = is_medium ? -RT_INFINITY : t_min;
+    real q_max = is_medium ? RT_INFINITY : closest_so_far;
+    real rec1_t = real(0.0);
     bool ok = true;
     const int n_query = is_medium ? 2 : 1;
     for (int q = 0; q < n_query; ++q) {
       geom_closest<F, COUNT, STACK, WALK>(sv, geom_rec, rq, q_min, q_max, &best, stack, cnt);
       if (!best.hit) { ok = false; break; }
-      if (q == 0) { rec1_t = best.t; q_min = rec1_t + 0.0001; }
+      if (q == 0) { rec1_t = best.t; q_min = rec1_t + real(0.0001); }
     }
     if (!ok) continue;
 
     // every accepted hit replaces the running record (range rejection already compared against
     // closest_so_far), so the record is built in place
     if (is_medium) {
-      double rec2_t = best.t;
-      double t1 = rt_fmax(rec1_t, t_min);
-      double t2 = rt_fmin(rec2_t, closest_so_far);
+      real rec2_t = best.t;
+      real t1 = rt_fmax(rec1_t, t_min);
+      real t2 = rt_fmin(rec2_t, closest_so_far);
       if (t1 >= t2) continue;
-      if (t1 < 0.0) t1 = 0.0;
-      double ray_length = length(r.direction);
-      double distance_inside_boundary = (t2 - t1) * ray_length;
-      double hit_distance = e->f[0] * rt_log(rng_f64(rng));
+      if (t1 < real(0.0)) t1 = real(0.0);
+      real ray_length = length(r.direction);
+      real distance_inside_boundary = (t2 - t1) * ray_length;
+      real hit_distance = e->f[0] * rt_log(rng_f64(rng));
       if (hit_distance > distance_inside_boundary) continue;
-      double t = t1 + hit_distance / ray_length;
+      real t = t1 + hit_distance / ray_length;
       rec->t = t;
       rec->p = ray_at(r, t);
       rec->normal = v3(0, 0, 0);
       rec->front_face = true;
-      rec->u = 0.0; rec->v = 0.0;
+      rec->u = real(0.0); rec->v = real(0.0);
       rec->mat = e->b;
     } else {
       prim_finalize<F>(sv, best.ref, rq, best.t, rec);

@@ -23,10 +23,10 @@ struct PathState {
 RT_HD void path_begin(const RenderParams& rp, uint32_t i, uint32_t j, uint32_t sample, PathState* ps) {
   uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.image_width + (uint64_t)i;
   ps->rng = rng_for_sample(rp.seed, pixel_index, sample);
-  double ru = rng_f64(ps->rng);
-  double u = ((double)i + ru) / (double)(rp.image_width - 1);
-  double rv = rng_f64(ps->rng);
-  double v = ((double)j + rv) / (double)(rp.image_height - 1);
+  real ru = rng_f64(ps->rng);
+  real u = ((real)i + ru) / (real)(rp.image_width - 1);
+  real rv = rng_f64(ps->rng);
+  real v = ((real)j + rv) / (real)(rp.image_height - 1);
   ps->ray = camera_get_ray(rp.cam, u, v, ps->rng);
   ps->product = v3(1, 1, 1);
   ps->output = v3(0, 0, 0);
@@ -68,7 +68,7 @@ RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps,
                      TraceCounters* cnt) {
   if (path_bounce_begin(ps)) return true;
   HitRecord rec;
-  bool hit = world_hit<F, COUNT, STACK, WALK>(sv, ps->ray, 0.001, RT_INFINITY, &rec, ps->rng, stack, cnt);
+  bool hit = world_hit<F, COUNT, STACK, WALK>(sv, ps->ray, real(0.001), RT_INFINITY, &rec, ps->rng, stack, cnt);
   return path_bounce_end<F, COUNT>(sv, rp, ps, hit, rec, cnt);
 }
 

@@ -93,16 +93,29 @@ RT_HD double u64_to_unit_f64(uint64_t x) {
   return (double)(x >> 11) * 0x1.0p-53;
 }
 
-// rng.gen::<f64>()
+// rng.gen::<f64>()  (real = float: the 24 high bits of the same 64-bit output, times 2^-24)
+#if defined(RT_F32)
+RT_HD real rng_f64(Rng& r) { return (float)(uint32_t)(rng_next_u64(r) >> 40) * 0x1.0p-24f; }
+#else
 RT_HD double rng_f64(Rng& r) { return u64_to_unit_f64(rng_next_u64(r)); }
+#endif
 // rng.gen_range(lo..hi) for f64: the [1,2) mantissa construction of rand 0.8.5's
 // UniformFloat<f64>::sample_single -- value1_2 * scale + (low - scale).
 RT_HD double u64_to_f64_1_2(uint64_t x) { return bits_f64((x >> 12) | 0x3FF0000000000000ull); }
+#if defined(RT_F32)
+RT_HD real rng_range(Rng& r, real lo, real hi) {  // the same [1,2) construction with the 23 mantissa bits of a float
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)(rng_next_u64(r) >> 41) | 0x3F800000u;
+  const float scale = hi - lo, offset = lo - scale;
+  return c.f * scale + offset;
+}
+#else
 RT_HD double rng_range(Rng& r, double lo, double hi) {
   double scale = hi - lo;
   double offset = lo - scale;
   return u64_to_f64_1_2(rng_next_u64(r)) * scale + offset;
 }
+#endif
 
 // SplitMix64: host-side generator for scene construction (random sphere
 // placement, box heights, Perlin tables, the oracle's reference-rule BVH axis).

@@ -53,9 +53,16 @@ inline T rt_load_uniform(const T* p) { return *p; }
 #define RT_DEVICE_CODE 0
 #endif
 
+// The arithmetic type of the path.  double = the parity build (everything above: bit-identical to the CPU oracle);
+// float = the fast mode, compiled as a second translation unit into namespace rt32 (hip/render_f32.hip):
+// same source, `real` = float, judged statistically, never against the oracle's bits.
+#ifndef RT_REAL
+#define RT_REAL double
+#endif
+
 namespace rt {
 
-typedef double real;
+typedef RT_REAL real;
 
 // Bit casts (memcpy-free so they stay in registers on the device).
 RT_HD uint64_t f64_bits(double x) {
@@ -70,7 +77,7 @@ RT_HD double f64_from_words(uint32_t hi, uint32_t lo) {
   return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
-#define RT_INFINITY (__builtin_huge_val())
+#define RT_INFINITY ((::rt::real)__builtin_huge_val())
 
 // IEEE-exact primitives used by the core.  sqrt/fabs/floor are correctly
 // rounded (or exact) on both x86-64 and gfx950, so they are safe to share.
@@ -81,6 +88,13 @@ RT_HD double rt_floor(double x) { return __builtin_floor(x); }
 RT_HD double rt_fmin(double a, double b) { return __builtin_fmin(a, b); }
 RT_HD double rt_fmax(double a, double b) { return __builtin_fmax(a, b); }
 RT_HD bool rt_isnan(double x) { return x != x; }
+// the same primitives for real = float
+RT_HD float rt_sqrt(float x) { return __builtin_sqrtf(x); }
+RT_HD float rt_fabs(float x) { return __builtin_fabsf(x); }
+RT_HD float rt_floor(float x) { return __builtin_floorf(x); }
+RT_HD float rt_fmin(float a, float b) { return __builtin_fminf(a, b); }
+RT_HD float rt_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+RT_HD bool rt_isnan(float x) { return x != x; }
 
 // Rust `x as i32` for f64: saturating, NaN -> 0 (vec3.rs:103-105, perlin.rs:33-35,
 // texture.rs:107-108).
@@ -90,5 +104,6 @@ RT_HD int32_t rt_f64_as_i32(double x) {
   if (x <= -2147483648.0) return (int32_t)(-2147483647 - 1);
   return (int32_t)x;
 }
+RT_HD int32_t rt_f64_as_i32(float x) { return rt_f64_as_i32((double)x); }
 
 }  // namespace rt

@@ -16,7 +16,7 @@
 
 namespace rt {
 
-#define RT_PI 3.14159265358979323846  // std::f64::consts::PI
+#define RT_PI ((::rt::real)3.14159265358979323846)  // std::f64::consts::PI
 
 namespace detail {
 
@@ -295,6 +295,17 @@ RT_HD double rt_atan2(double y, double x) {
 }
 
 // f64::to_radians (camera.rs:26, hit.rs:844): x * (PI / 180)
-RT_HD double rt_to_radians(double deg) { return deg * (RT_PI / 180.0); }
+RT_HD double rt_to_radians(double deg) { return deg * (3.14159265358979323846 / 180.0); }
+
+// real = float (the fast mode, hip/render_f32.hip): the platform's single-precision functions; no parity claim there.
+RT_HD float rt_sin(float x) { return __builtin_sinf(x); }
+RT_HD float rt_cos(float x) { return __builtin_cosf(x); }
+RT_HD float rt_log(float x) { return __builtin_logf(x); }
+RT_HD float rt_acos(float x) { return __builtin_acosf(x); }
+RT_HD float rt_atan2(float y, float x) { return __builtin_atan2f(y, x); }
+RT_HD int rt_sin_sign(float x) {
+  const float s = __builtin_sinf(x);
+  return s != s ? 2 : (s > 0.0f ? 1 : (s < 0.0f ? -1 : 0));
+}
 
 }  // namespace rt

@@ -10,18 +10,18 @@ namespace rt {
 
 // vec3.rs:273-276
 RT_HD Vec3 random_vec3(Rng& g) {
-  double x = rng_f64(g), y = rng_f64(g), z = rng_f64(g);
+  real x = rng_f64(g), y = rng_f64(g), z = rng_f64(g);
   return v3(x, y, z);
 }
 // vec3.rs:278-285
-RT_HD Vec3 random_range_vec3(Rng& g, double mn, double mx) {
-  double x = rng_range(g, mn, mx), y = rng_range(g, mn, mx), z = rng_range(g, mn, mx);
+RT_HD Vec3 random_range_vec3(Rng& g, real mn, real mx) {
+  real x = rng_range(g, mn, mx), y = rng_range(g, mn, mx), z = rng_range(g, mn, mx);
   return v3(x, y, z);
 }
 // One iteration of random_in_unit_sphere's rejection loop (vec3.rs:288-294): three draws, accept test.
 RT_HD bool sphere_sample_try(Rng& g, Vec3* p) {
-  *p = random_range_vec3(g, -1.0, 1.0);
-  return length_squared(*p) < 1.0;
+  *p = random_range_vec3(g, -real(1.0), real(1.0));
+  return length_squared(*p) < real(1.0);
 }
 // vec3.rs:287-295
 RT_HD Vec3 random_in_unit_sphere(Rng& g) {
@@ -35,34 +35,34 @@ RT_HD Vec3 random_unit_vector(Rng& g) { return unit(random_in_unit_sphere(g)); }
 // vec3.rs:310-322
 RT_HD Vec3 random_in_unit_disk(Rng& g) {
   for (;;) {
-    double x = rng_range(g, -1.0, 1.0), y = rng_range(g, -1.0, 1.0);
-    Vec3 p = v3(x, y, 0.0);
-    if (length_squared(p) < 1.0) return p;
+    real x = rng_range(g, -real(1.0), real(1.0)), y = rng_range(g, -real(1.0), real(1.0));
+    Vec3 p = v3(x, y, real(0.0));
+    if (length_squared(p) < real(1.0)) return p;
   }
 }
 
 // camera.rs:59-71.  The lens sample and the shutter time are drawn even when
 // aperture is 0 / the shutter interval is a single instant's worth.
-RT_HD Ray camera_get_ray(const FlatCamera& c, double s, double t, Rng& g) {
+RT_HD Ray camera_get_ray(const FlatCamera& c, real s, real t, Rng& g) {
   Vec3 rd = c.lens_radius * random_in_unit_disk(g);
   Vec3 offset = c.u * rd.x + c.v * rd.y;
   Point3 origin = c.origin + offset;
   Vec3 direction = c.lower_left_corner + s * c.horizontal + t * c.vertical - c.origin - offset;
-  double time = rng_range(g, c.time1, c.time2);
+  real time = rng_range(g, c.time1, c.time2);
   return make_ray(origin, direction, time);
 }
 
 // perlin.rs:28-52 + 85-106 (gradient fetch fused into the interpolation loop; same values).
 template <bool COUNT>
-RT_HD double perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
+RT_HD real perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
   if (COUNT) cnt->perlin_calls++;
-  double fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
-  double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  real fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
+  real u = p.x - fx, v = p.y - fy, w = p.z - fz;
   uint32_t i = (uint32_t)rt_f64_as_i32(fx), j = (uint32_t)rt_f64_as_i32(fy), k = (uint32_t)rt_f64_as_i32(fz);
-  double uu = u * u * (3.0 - 2.0 * u);
-  double vv = v * v * (3.0 - 2.0 * v);
-  double ww = w * w * (3.0 - 2.0 * w);
-  double accum = 0.0;
+  real uu = u * u * (real(3.0) - real(2.0) * u);
+  real vv = v * v * (real(3.0) - real(2.0) * v);
+  real ww = w * w * (real(3.0) - real(2.0) * w);
+  real accum = real(0.0);
   RT_NO_UNROLL
   for (uint32_t di = 0; di < 2; ++di)
     RT_NO_UNROLL
@@ -71,25 +71,25 @@ RT_HD double perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
       for (uint32_t dk = 0; dk < 2; ++dk) {
         int32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
         Vec3 c = load_v3(pn.ranvec[h]);
-        double i1 = (double)di, j1 = (double)dj, k1 = (double)dk;
+        real i1 = (real)di, j1 = (real)dj, k1 = (real)dk;
         Vec3 weight_v = v3(u - i1, v - j1, w - k1);
-        accum += (i1 * uu + (1.0 - i1) * (1.0 - uu)) * (j1 * vv + (1.0 - j1) * (1.0 - vv)) *
-                 (k1 * ww + (1.0 - k1) * (1.0 - ww)) * dot(c, weight_v);
+        accum += (i1 * uu + (real(1.0) - i1) * (real(1.0) - uu)) * (j1 * vv + (real(1.0) - j1) * (real(1.0) - vv)) *
+                 (k1 * ww + (real(1.0) - k1) * (real(1.0) - ww)) * dot(c, weight_v);
       }
   return accum;
 }
 
 // perlin.rs:54-66
 template <bool COUNT>
-RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceCounters* cnt) {
-  double accum = 0.0;
+RT_HD real perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceCounters* cnt) {
+  real accum = real(0.0);
   Point3 temp_p = p;
-  double weight = 1.0;
+  real weight = real(1.0);
   RT_NO_UNROLL
   for (int i = 0; i < depth; ++i) {
     accum += weight * perlin_noise<COUNT>(pn, temp_p, cnt);
-    weight *= 0.5;
-    temp_p = temp_p * 2.0;
+    weight *= real(0.5);
+    temp_p = temp_p * real(2.0);
   }
   return rt_fabs(accum);
 }
@@ -97,30 +97,30 @@ RT_HD double perlin_turbulence(const FlatPerlin& pn, Point3 p, int depth, TraceC
 // The two expensive, rarely reached texture kinds, kept out of line so that their registers and
 // code do not weigh on the bounce loop (Noise: 7 Perlin octaves; Image: a texel fetch).
 template <bool COUNT>
-RT_HD Color texture_value_cold(const SceneView& sv, const FlatTexture& t, double u, double v, Point3 p,
+RT_HD Color texture_value_cold(const SceneView& sv, const FlatTexture& t, real u, real v, Point3 p,
                                         TraceCounters* cnt) {
   if (t.kind == TEX_NOISE) {  // texture.rs:80-88
-    double s = 1.0 + rt_sin(t.scale * p.z + 10.0 * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
-    return v3(1.0, 1.0, 1.0) * 0.5 * s;
+    real s = real(1.0) + rt_sin(t.scale * p.z + real(10.0) * perlin_turbulence<COUNT>(sv.perlins[t.a], p, 7, cnt));
+    return v3(real(1.0), real(1.0), real(1.0)) * real(0.5) * s;
   }
   // TEX_IMAGE, texture.rs:102-121
   if (COUNT) cnt->texels++;
   const FlatImage& im = sv.images[t.a];
-  double uc = clamp(u, 0.0, 1.0);
-  double vc = 1.0 - clamp(v, 0.0, 1.0);
-  int32_t i = rt_f64_as_i32(uc * (double)im.width);
-  int32_t j = rt_f64_as_i32(vc * (double)im.height);
+  real uc = clamp(u, real(0.0), real(1.0));
+  real vc = real(1.0) - clamp(v, real(0.0), real(1.0));
+  int32_t i = rt_f64_as_i32(uc * (real)im.width);
+  int32_t j = rt_f64_as_i32(vc * (real)im.height);
   i = i < im.width - 1 ? i : im.width - 1;
   j = j < im.height - 1 ? j : im.height - 1;
-  const double color_scale = 1.0 / 255.0;
-  const double* px = sv.texels + 3 * (im.first_texel + (int64_t)j * im.width + i);
+  const real color_scale = real(1.0) / real(255.0);
+  const real* px = sv.texels + 3 * (im.first_texel + (int64_t)j * im.width + i);
   return v3(color_scale * px[0], color_scale * px[1], color_scale * px[2]);
 }
 
 // Texture::value for the whole texture tree (texture.rs:27-31, 54-64, 80-88, 102-121).
 // Checker picks a child from p alone, so nested checkers resolve iteratively.
 template <uint32_t F, bool COUNT>
-RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, Point3 p,
+RT_HD Color texture_value(const SceneView& sv, int32_t tex, real u, real v, Point3 p,
                           TraceCounters* cnt) {
   if (F & F_CHECKER) {
     for (int guard = 0; guard < 16; ++guard) {
@@ -128,7 +128,7 @@ RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, 
       if (t.kind != TEX_CHECKER) break;
       // texture.rs:56-62: sines = sin(10x) sin(10y) sin(10z); sines < 0 -> odd.  Only the sign is used, and
       // rt_sin_sign gives exactly the sign rt_sin would have (a NaN or a zero factor makes the test false).
-      int sx = rt_sin_sign(10.0 * p.x), sy = rt_sin_sign(10.0 * p.y), sz = rt_sin_sign(10.0 * p.z);
+      int sx = rt_sin_sign(real(10.0) * p.x), sy = rt_sin_sign(real(10.0) * p.y), sz = rt_sin_sign(real(10.0) * p.z);
       bool negative = sx != 2 && sy != 2 && sz != 2 && sx * sy * sz < 0;
       tex = negative ? t.b : t.a;
     }
@@ -141,13 +141,13 @@ RT_HD Color texture_value(const SceneView& sv, int32_t tex, double u, double v, 
 
 // hit.rs:1095-1099;  f64::powi(x, 5) == x * (x*x) * (x*x) evaluated as ((x^2)^2)*x by
 // LLVM's powi expansion (square-and-multiply from the low bit: r = x; x2 = x*x; x4 = x2*x2; r*x4).
-RT_HD double reflectance(double cosine, double ref_idx) {
-  double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+RT_HD real reflectance(real cosine, real ref_idx) {
+  real r0 = (real(1.0) - ref_idx) / (real(1.0) + ref_idx);
   r0 = r0 * r0;
-  double b = 1.0 - cosine;
-  double b2 = b * b;
-  double b4 = b2 * b2;
-  return r0 + (1.0 - r0) * (b * b4);
+  real b = real(1.0) - cosine;
+  real b2 = b * b;
+  real b4 = b2 * b2;
+  return r0 + (real(1.0) - r0) * (b * b4);
 }
 
 // Material::emitted (hit.rs:1015-1017 default, 1149-1151 DiffuseLight).
@@ -186,14 +186,14 @@ RT_HD bool material_scatter_with_sample(const SceneView& sv, const FlatMaterial&
     Vec3 dir = reflected + m.param * sphere_sample;
     *scattered = make_ray(rec.p, dir, r_in.time);
     *attenuation = load_v3(m.albedo);
-    return dot(dir, rec.normal) > 0.0;
+    return dot(dir, rec.normal) > real(0.0);
   }
   if ((F & F_DIELECTRIC) && m.kind == MAT_DIELECTRIC) {  // hit.rs:1103-1126 (uniform drawn only if refraction is possible)
-    double refraction_ratio = rec.front_face ? (1.0 / m.param) : m.param;
+    real refraction_ratio = rec.front_face ? (real(1.0) / m.param) : m.param;
     Vec3 unit_direction = unit(r_in.direction);
-    double cos_theta = rt_fmin(dot(-unit_direction, rec.normal), 1.0);
-    double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
-    bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+    real cos_theta = rt_fmin(dot(-unit_direction, rec.normal), real(1.0));
+    real sin_theta = rt_sqrt(real(1.0) - cos_theta * cos_theta);
+    bool cannot_refract = refraction_ratio * sin_theta > real(1.0);
     Vec3 direction;
     if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_f64(g))
       direction = reflect(unit_direction, rec.normal);
