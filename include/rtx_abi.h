@@ -180,6 +180,14 @@ rtx_status rtx_flat_info(const rtx_flat* f, RtxFlatInfo* out);
 int32_t rtx_flat_top_level_kind(const rtx_flat* f, int32_t index);
 /* Copies every array to the CURRENT HIP device. */
 rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out);
+/* The statistical fast mode.  The same scene, narrowed field by field to single precision, rendered by
+ * the same kernels compiled with float arithmetic (csrc/hip/render_f32.hip): the image converges to the same picture
+ * but is NOT bit-comparable with the reference's -- the bit-exactness this header promises elsewhere is about scenes
+ * uploaded with rtx_scene_upload.  Every render entry point takes either kind of scene; rtx_render_count and
+ * rtx_multi_* are f64 only.  The RNG stream per (pixel, sample), the sample order of the sums and the f64 accumulators
+ * handed back are the same in both modes. */
+rtx_status rtx_scene_upload_f32(const rtx_flat* f, rtx_scene** out);
+int32_t rtx_scene_is_f32(const rtx_scene* s);
 void rtx_scene_destroy(rtx_scene* s); /* NULL-safe */
 /* Releases the render workspace of an idle scene (it is re-allocated by the next render); the geometry stays resident. */
 rtx_status rtx_scene_trim(rtx_scene* s);

@@ -137,6 +137,8 @@ ABI = {
     "rtx_flat_destroy": (None, [_VP]),
     "rtx_flat_info": (C.c_int32, [_VP, C.POINTER(RtxFlatInfo)]),
     "rtx_scene_upload": (C.c_int32, [_VP, C.POINTER(_VP)]),
+    "rtx_scene_upload_f32": (C.c_int32, [_VP, C.POINTER(_VP)]),
+    "rtx_scene_is_f32": (C.c_int32, [_VP]),
     "rtx_scene_destroy": (None, [_VP]),
     "rtx_render": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.POINTER(RtxFrame)]),
     "rtx_shard_rows": (C.c_int32, [C.POINTER(RtxConfig), C.POINTER(RtxShard)]),
@@ -386,17 +388,22 @@ class Flat:
         n = self.info()["n_top_level"]
         return [lib.rtx_flat_top_level_kind(self._p, i) for i in range(n)]
 
-    def upload(self):
-        return Scene(self)
+    def upload(self, f32=False):
+        """f32=True: the statistical fast mode (rtx_scene_upload_f32): float arithmetic, no bit-exactness claim."""
+        return Scene(self, f32=f32)
 
 
 class Scene:
     """Scene resident on the current HIP device (rtx_scene)."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, f32=False):
         p = _VP()
-        _check(lib.rtx_scene_upload(flat.ptr, C.byref(p)))
+        _check((lib.rtx_scene_upload_f32 if f32 else lib.rtx_scene_upload)(flat.ptr, C.byref(p)))
         self._p = p
+
+    @property
+    def is_f32(self):
+        return bool(lib.rtx_scene_is_f32(self._p))
 
     def __del__(self):
         p, self._p = getattr(self, "_p", None), None

@@ -18,6 +18,7 @@ APP_PATH = os.path.join(LIB_DIR, "rtx_render")
 
 HIP_SOURCES = [
     "csrc/hip/render.hip",
+    "csrc/hip/render_f32.hip",   # render.hip again with real = float (the statistical fast mode)
     "csrc/hip/lbvh.hip",
     "csrc/hip/abi.cpp",
     "csrc/host/scene_graph.cpp",
@@ -57,8 +58,27 @@ def build_library(force=False, verbose=True):
     deps = [os.path.join(PKG_DIR, "csrc"), os.path.join(REPO_DIR, "include")]
     if not force and not needs_build(LIB_PATH, deps):
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIP_FLAGS + ["-shared"] + [os.path.join(PKG_DIR, s) for s in HIP_SOURCES] + ["-o", LIB_PATH]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    # one object per source, compiled side by side (the two compilations of render.hip dominate), then one link
+    jobs = []
+    for src in HIP_SOURCES:
+        obj = os.path.join(obj_dir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        if force or needs_build(obj, deps):
+            cmd = [_hipcc()] + HIP_FLAGS + ["-c", os.path.join(PKG_DIR, src), "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=PKG_DIR)))
+        else:
+            jobs.append((None, None))
+    for cmd, proc in jobs:
+        if proc is not None and proc.wait() != 0:
+            for _, other in jobs:
+                if other is not None:
+                    other.wait()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    objs = [os.path.join(obj_dir, os.path.basename(src).rsplit(".", 1)[0] + ".o") for src in HIP_SOURCES]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB_PATH]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=PKG_DIR)

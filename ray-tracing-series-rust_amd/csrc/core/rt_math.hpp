@@ -297,15 +297,18 @@ RT_HD double rt_atan2(double y, double x) {
 // f64::to_radians (camera.rs:26, hit.rs:844): x * (PI / 180)
 RT_HD double rt_to_radians(double deg) { return deg * (3.14159265358979323846 / 180.0); }
 
-// real = float (the fast mode, hip/render_f32.hip): the platform's single-precision functions; no parity claim there.
-RT_HD float rt_sin(float x) { return __builtin_sinf(x); }
-RT_HD float rt_cos(float x) { return __builtin_cosf(x); }
-RT_HD float rt_log(float x) { return __builtin_logf(x); }
-RT_HD float rt_acos(float x) { return __builtin_acosf(x); }
-RT_HD float rt_atan2(float y, float x) { return __builtin_atan2f(y, x); }
+#if defined(RT_F32)
+// real = float (the fast mode, hip/render_f32.hip, which includes <cmath>): the platform's single-precision functions;
+// no parity claim there.
+RT_HD float rt_sin(float x) { return ::sinf(x); }
+RT_HD float rt_cos(float x) { return ::cosf(x); }
+RT_HD float rt_log(float x) { return ::logf(x); }
+RT_HD float rt_acos(float x) { return ::acosf(x); }
+RT_HD float rt_atan2(float y, float x) { return ::atan2f(y, x); }
 RT_HD int rt_sin_sign(float x) {
-  const float s = __builtin_sinf(x);
+  const float s = ::sinf(x);
   return s != s ? 2 : (s > 0.0f ? 1 : (s < 0.0f ? -1 : 0));
 }
+#endif
 
 }  // namespace rt

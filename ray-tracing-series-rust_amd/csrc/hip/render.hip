@@ -25,7 +25,14 @@
 #include "../core/cull32.hpp"
 #include "../core/integrator.hpp"
 #include "../host/flat_scene.hpp"
+#include "f32_bridge.hpp"
+#ifndef RTX_F32_TU
 #include "abi_internal.hpp"
+#else
+// The f32 compilation of this file (render_f32.hip) sees none of the C ABI's handle types: it exports the four
+// functions of f32_bridge.hpp and render.hip proper owns the handles.
+namespace rtx { void set_error(const std::string& msg); }
+#endif
 
 namespace rtx {
 
@@ -192,7 +199,7 @@ static int shard_row_count(int32_t height, const RtxShard& sh, int32_t row_limit
   return n;
 }
 
-static rtx_status validate(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
+static rtx_status validate(const void* s, const RtxCamera* cam, const RtxConfig* cfg,
                            const RtxShard* shard, RtxShard* sh_out) {
   if (!s || !cam || !cfg) { set_error("render: NULL scene, camera or config"); return RTX_EINVAL; }
   if (cfg->threads <= 0 || cfg->image_width <= 0 || cfg->samples_per_pixel <= 0 || cfg->max_depth <= 0) {
@@ -213,8 +220,8 @@ static rtx_status validate(const rtx_scene* s, const RtxCamera* cam, const RtxCo
 
 static rt::RenderParams make_params(const RtxCamera* cam, const RtxConfig* cfg) {
   rt::RenderParams rp;
-  static_assert(sizeof(RtxCamera) == sizeof(rt::FlatCamera), "camera layout");
-  memcpy(&rp.cam, cam, sizeof(rt::FlatCamera));
+  static_assert(sizeof(RtxCamera) == 24 * sizeof(double) && sizeof(rt::FlatCamera) == 24 * sizeof(rt::real), "camera layout");
+  for (int k = 0; k < 24; ++k) ((rt::real*)&rp.cam)[k] = (rt::real)((const double*)cam)[k];
   rp.background = rt::v3(cfg->background[0], cfg->background[1], cfg->background[2]);
   rp.image_width = cfg->image_width;
   rp.image_height = rtx_image_height(cfg);
@@ -225,13 +232,12 @@ static rt::RenderParams make_params(const RtxCamera* cam, const RtxConfig* cfg) 
 }
 
 template <bool COUNT>
-static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, const RtxConfig* cfg,
+static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxConfig* cfg,
                               const RtxShard* shard, double* d_accum_out, uint8_t* d_rgb8_out,
                               hipStream_t stream, RtxRenderStats* stats) {
   RtxShard sh;
-  rtx_status st = validate(scene, cam, cfg, shard, &sh);
+  rtx_status st = validate(ds, cam, cfg, shard, &sh);
   if (st != RTX_OK) return st;
-  DeviceScene* ds = scene_device(scene);
   int cur = -1;
   HIP_TRY(hipGetDevice(&cur));
   if (cur != ds->device) { set_error("render: scene was uploaded to a different device than the current one"); return RTX_EINVAL; }
@@ -447,7 +453,7 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
         const bool book2 = (feat & ~P_BOOK2) == 0;
         const bool has_gravity = (feat & rt::F_GRAVITY_SPHERE) != 0;
         const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
-        const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(double);
+        const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : 1)][wide ? 1 : 0];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
@@ -544,16 +550,9 @@ static rtx_status render_impl(const rtx_scene* scene, const RtxCamera* cam, cons
   return RTX_OK;
 }
 
-}  // namespace rtx
-
-using namespace rtx;
-
-extern "C" {
-
-rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
-  if (!f || !out) { set_error("rtx_scene_upload: NULL argument"); return RTX_EINVAL; }
+// Upload one flattened scene to the current device and size the launches of every kernel for it.
+static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
   *out = nullptr;
-  const FlatScene& fs = *flat_of(f);
   DeviceScene* ds = new (std::nothrow) DeviceScene();
   if (!ds) { set_error("out of memory"); return RTX_ENOMEM; }
   hipError_t e = hipGetDevice(&ds->device);
@@ -685,7 +684,7 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
       if (wth && atoi(wth) >= 0 && atoi(wth) <= 64) ds->world_threshold = (uint32_t)atoi(wth);
       for (int wd = 0; wd < 2; ++wd) {
         const uint32_t levels = (uint32_t)(wd ? ds->wide_levels : fs.max_stack + 1);
-        const size_t wl = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(double);
+        const size_t wl = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
         if (wl > 64 * 1024) continue;
         int n = 0;
 #define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
@@ -789,13 +788,11 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
     const char* wt = getenv("RTX_WALK_THRESHOLD");
     if (wt && atoi(wt) >= 1 && atoi(wt) <= 64) ds->walk_threshold = (uint32_t)atoi(wt);
   }
-  *out = make_scene_handle(ds);
+  *out = ds;
   return RTX_OK;
 }
 
-rtx_status rtx_scene_trim(rtx_scene* s) {
-  if (!s) { set_error("rtx_scene_trim: NULL scene"); return RTX_EINVAL; }
-  DeviceScene* ds = scene_device(s);
+static rtx_status scene_trim_impl(DeviceScene* ds) {
   int cur = -1;
   HIP_TRY(hipGetDevice(&cur));
   if (cur != ds->device) { set_error("rtx_scene_trim: scene lives on a different device than the current one"); return RTX_EINVAL; }
@@ -805,22 +802,74 @@ rtx_status rtx_scene_trim(rtx_scene* s) {
   return RTX_OK;
 }
 
+}  // namespace rtx
+
+using namespace rtx;
+
+#ifdef RTX_F32_TU
+#include "f32_entry.inc"   // the f32 compilation's side of f32_bridge.hpp
+#else
+#include "f32_convert.inc" // f64 flat arrays -> the f32 compilation's layouts
+
+// Every render entry point funnels through here: the scene handle says which compilation owns the device scene.
+template <bool COUNT>
+static rtx_status render_any(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg, const RtxShard* shard,
+                             double* d_accum_rgb, uint8_t* d_rgb8, hipStream_t stream, RtxRenderStats* stats) {
+  if (!s) { set_error("render: NULL scene, camera or config"); return RTX_EINVAL; }
+  if (s->f32) {
+    if (COUNT) { set_error("rtx_render_count: the work counters belong to the f64 path (upload the scene with rtx_scene_upload)"); return RTX_EUNSUPPORTED; }
+    return rtx_f32_render(s->device_scene, cam, cfg, shard, d_accum_rgb, d_rgb8, (void*)stream, stats);
+  }
+  return render_impl<COUNT>(scene_device(s), cam, cfg, shard, d_accum_rgb, d_rgb8, stream, stats);
+}
+
+extern "C" {
+
+rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out) {
+  if (!f || !out) { set_error("rtx_scene_upload: NULL argument"); return RTX_EINVAL; }
+  *out = nullptr;
+  DeviceScene* ds = nullptr;
+  rtx_status st = scene_upload_impl(*flat_of(f), &ds);
+  if (st != RTX_OK) return st;
+  *out = make_scene_handle(ds, 0);
+  return RTX_OK;
+}
+
+rtx_status rtx_scene_upload_f32(const rtx_flat* f, rtx_scene** out) {
+  if (!f || !out) { set_error("rtx_scene_upload_f32: NULL argument"); return RTX_EINVAL; }
+  *out = nullptr;
+  void* ds32 = nullptr;
+  rtx_status st = upload_as_f32(*flat_of(f), &ds32);
+  if (st != RTX_OK) return st;
+  *out = make_scene_handle((DeviceScene*)ds32, 1);
+  return RTX_OK;
+}
+
+int32_t rtx_scene_is_f32(const rtx_scene* s) { return s && s->f32 ? 1 : 0; }
+
+rtx_status rtx_scene_trim(rtx_scene* s) {
+  if (!s) { set_error("rtx_scene_trim: NULL scene"); return RTX_EINVAL; }
+  if (s->f32) return rtx_f32_trim(s->device_scene);
+  return scene_trim_impl(scene_device(s));
+}
+
 void rtx_scene_destroy(rtx_scene* s) {
   if (!s) return;
-  free_device_scene(scene_device(s));
+  if (s->f32) rtx_f32_destroy(s->device_scene);
+  else free_device_scene(scene_device(s));
   free_scene_handle(s);
 }
 
 rtx_status rtx_render_device(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
                              const RtxShard* shard, double* d_accum_rgb, uint8_t* d_rgb8,
                              void* hip_stream, RtxRenderStats* stats) {
-  return render_impl<false>(s, cam, cfg, shard, d_accum_rgb, d_rgb8, (hipStream_t)hip_stream, stats);
+  return render_any<false>(s, cam, cfg, shard, d_accum_rgb, d_rgb8, (hipStream_t)hip_stream, stats);
 }
 
 rtx_status rtx_render_count(const rtx_scene* s, const RtxCamera* cam, const RtxConfig* cfg,
                             const RtxShard* shard, RtxRenderStats* stats) {
   if (!stats) { set_error("rtx_render_count: stats is NULL"); return RTX_EINVAL; }
-  return render_impl<true>(s, cam, cfg, shard, nullptr, nullptr, (hipStream_t) nullptr, stats);
+  return render_any<true>(s, cam, cfg, shard, nullptr, nullptr, (hipStream_t) nullptr, stats);
 }
 
 rtx_status rtx_device_math(int32_t fn, const double* x, const double* y, int64_t n, double* out) {
@@ -872,7 +921,7 @@ rtx_status rtx_render(const rtx_scene* s, const RtxCamera* cam, const RtxConfig*
     set_error("rtx_render: hipMalloc of the frame failed");
     return RTX_EHIP;
   }
-  st = render_impl<false>(s, cam, cfg, nullptr, d_accum, d_rgb, (hipStream_t) nullptr, nullptr);
+  st = render_any<false>(s, cam, cfg, nullptr, d_accum, d_rgb, (hipStream_t) nullptr, nullptr);
   if (st == RTX_OK) {
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess && out->accum_rgb) e = hipMemcpy(out->accum_rgb, d_accum, npix * 24, hipMemcpyDeviceToHost);
@@ -917,3 +966,4 @@ extern "C" rtx_status rtx_render_scene_with_time(const rtx_scene* s, double t0, 
 }
 
 #include "multi.inc"  // rtx_multi_*: one process, several GPUs, one RCCL gather
+#endif  // !RTX_F32_TU

@@ -22,10 +22,10 @@ struct FlatScene {
   std::vector<rt::FlatTexture> textures;
   std::vector<rt::FlatPerlin> perlins;
   std::vector<rt::FlatImage> images;
-  std::vector<double> texels;
+  std::vector<rt::real> texels;
   std::vector<float> top_box32;  // 6 per top-level slot (SceneView::top_box32)
   std::vector<rt::FlatGravitySphere> gravity_spheres;
-  std::vector<double> gravity_y;
+  std::vector<rt::real> gravity_y;
   int32_t max_stack = 0;      // deepest BVH (number of stacked far children a walk can hold)
   int32_t n_bvh = 0;
   uint32_t features = 0;      // rt::Feature bits reachable in this scene
