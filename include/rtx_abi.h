@@ -282,7 +282,8 @@ rtx_status rtx_write_ppm(const char* path, int32_t width, int32_t height, const 
 /* Evaluates one arithmetic building block of the kernels ON THE GPU for n host-side operands
  * (copied in and out), so tests can prove it is bit-identical to the host's evaluation of the same
  * source.  fn: 0 sin, 1 cos, 2 log, 3 acos, 4 atan2(x,y), 5 tan, 6 sqrt, 7 x/y, 8 x*y+x (must NOT be
- * fused), 9 floor.  rtx_device_stream: the first n uniforms of the (seed, pixel, sample) stream. */
+ * fused), 9 floor, 10 the sort key of a 4-wide BVH step for entry distance x and t_min y
+ * (clamp into [y, 3e38] with NaN -> y).  rtx_device_stream: the first n uniforms of the (seed, pixel, sample) stream. */
 rtx_status rtx_device_math(int32_t fn, const double* x, const double* y, int64_t n, double* out);
 rtx_status rtx_device_stream(uint64_t seed, uint64_t pixel, uint32_t sample, int32_t n, double* out);
 

@@ -493,7 +493,7 @@ def trace_kernel_name(kernel):
 
 def device_math(fn, x, y=None):
     """Evaluate one arithmetic building block on the GPU (see rtx_device_math)."""
-    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6, "div": 7, "muladd": 8, "floor": 9}
+    names = {"sin": 0, "cos": 1, "log": 2, "acos": 3, "atan2": 4, "tan": 5, "sqrt": 6, "div": 7, "muladd": 8, "floor": 9, "wide_key": 10}
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y if y is not None else np.ones_like(x), dtype=np.float64)
     out = np.empty_like(x)

@@ -51,10 +51,31 @@ RT_HD Ray32 make_ray32(const Ray& r, real t_min) {
   q.iy = (float)(1.0 / r.direction.y);
   q.iz = (float)(1.0 / r.direction.z);
 #endif
+#if defined(RT_F32)
+  // Single-precision rays do have direction components of exactly 0 (a cancellation leaves nothing below one ulp), a few in
+  // every 10^8 rays.  With 1/d = inf the planes of that axis come out as +-inf or NaN, the widening below becomes inf and no
+  // box can be ruled out any more: such a ray walked the WHOLE tree, alone in its wave (the dragon room: 4 rays, 0.4 s).
+  // The fast mode gives the axis a finite slope of 2^-60 instead: a ray outside the slab sees both planes at the same huge
+  // distance and is culled, a ray inside sees (-huge, +huge).  The axis is left out of the error term like an infinite one
+  // (its distances only matter through their sign).
+  const float slope_cap = 0x1.0p60f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  q.ix = __builtin_amdgcn_fmed3f(q.ix, -slope_cap, slope_cap);
+  q.iy = __builtin_amdgcn_fmed3f(q.iy, -slope_cap, slope_cap);
+  q.iz = __builtin_amdgcn_fmed3f(q.iz, -slope_cap, slope_cap);
+#else
+  q.ix = __builtin_fminf(__builtin_fmaxf(q.ix, -slope_cap), slope_cap);
+  q.iy = __builtin_fminf(__builtin_fmaxf(q.iy, -slope_cap), slope_cap);
+  q.iz = __builtin_fminf(__builtin_fmaxf(q.iz, -slope_cap), slope_cap);
+#endif
+  const float finite_slope = 0x1.0p60f;
+#else
+  const float finite_slope = 1e30f;
+#endif
   q.oix = ox * q.ix; q.oiy = oy * q.iy; q.oiz = oz * q.iz;
-  float ax = __builtin_fabsf(q.ix) < 1e30f ? __builtin_fabsf(q.oix) : 0.0f;
-  float ay = __builtin_fabsf(q.iy) < 1e30f ? __builtin_fabsf(q.oiy) : 0.0f;
-  float az = __builtin_fabsf(q.iz) < 1e30f ? __builtin_fabsf(q.oiz) : 0.0f;
+  float ax = __builtin_fabsf(q.ix) < finite_slope ? __builtin_fabsf(q.oix) : 0.0f;
+  float ay = __builtin_fabsf(q.iy) < finite_slope ? __builtin_fabsf(q.oiy) : 0.0f;
+  float az = __builtin_fabsf(q.iz) < finite_slope ? __builtin_fabsf(q.oiz) : 0.0f;
   q.err2 = __builtin_fmaxf(ax, __builtin_fmaxf(ay, az)) * 0x1.0p-20f;
   // rounded DOWN whatever the sign (a medium's second boundary query may start at a negative t)
   q.t_min = (float)t_min * (t_min >= 0.0 ? 0.99999988f : 1.00000012f);

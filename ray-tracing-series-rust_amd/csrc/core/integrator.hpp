@@ -40,6 +40,14 @@ RT_HD void path_begin(const RenderParams& rp, uint32_t i, uint32_t j, uint32_t s
 // Both return true when the path has ended and ps->output holds the sample's radiance.
 RT_HD bool path_bounce_begin(PathState* ps) {
   ps->depth -= 1;
+#if defined(RT_F32)
+  // A ray that is not finite (a plane hit at t = inf behind a direction component of exactly 0 -- single-precision rays
+  // have those -- leaves a NaN hit point) can hit nothing, yet no box test can rule it out: it would visit every node and
+  // every primitive of every BVH, alone in its wave.  The fast mode ends such a path with what it has gathered.
+  const real mag = rt_fabs(ps->ray.origin.x) + rt_fabs(ps->ray.origin.y) + rt_fabs(ps->ray.origin.z) +
+                   rt_fabs(ps->ray.direction.x) + rt_fabs(ps->ray.direction.y) + rt_fabs(ps->ray.direction.z);
+  if (!(mag < RT_INFINITY)) return true;
+#endif
   return ps->depth < 0;
 }
 
@@ -68,7 +76,7 @@ RT_HD bool path_step(const SceneView& sv, const RenderParams& rp, PathState* ps,
                      TraceCounters* cnt) {
   if (path_bounce_begin(ps)) return true;
   HitRecord rec;
-  bool hit = world_hit<F, COUNT, STACK, WALK>(sv, ps->ray, real(0.001), RT_INFINITY, &rec, ps->rng, stack, cnt);
+  bool hit = world_hit<F, COUNT, STACK, WALK>(sv, ps->ray, ray_t_min(ps->ray), RT_INFINITY, &rec, ps->rng, stack, cnt);
   return path_bounce_end<F, COUNT>(sv, rp, ps, hit, rec, cnt);
 }
 

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../../include/rtx_abi.h"
@@ -413,18 +414,24 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
           // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
           if (ds->vote_diag && (feat & ~P_MESH_ROOM) == 0) {
             if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
+            HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH_ROOM, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
                                stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
                                ds->diag, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
                                (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base);
             HIP_TRY(hipStreamSynchronize(stream));
-            unsigned long long h[12];
+            unsigned long long h[24];
             HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
             const char* names[6] = {"outer", "regen", "node_step", "leaf_step", "shade_hit", "shade_all"};
             for (int k = 0; k < 6; ++k)
               fprintf(stderr, "[vote_diag] %-10s executions %llu lanes %llu mean lanes %.2f\n", names[k], h[2 * k], h[2 * k + 1],
                       h[2 * k] ? (double)h[2 * k + 1] / (double)h[2 * k] : 0.0);
+            if (h[12]) {
+              float v[12];
+              for (int k = 0; k < 6; ++k) { uint32_t lo = (uint32_t)h[13 + k], hi = (uint32_t)(h[13 + k] >> 32); memcpy(&v[2 * k], &lo, 4); memcpy(&v[2 * k + 1], &hi, 4); }
+              fprintf(stderr, "[vote_diag] %llu walks of >= 50000 node steps; the first: origin (%g %g %g) direction (%g %g %g) 1/d (%g %g %g) err2 %g t_min %g t_max %g depth left %llu\n",
+                      h[12], v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], h[19]);
+            }
           }
           else if ((feat & ~P_MESH_ROOM) == 0) { LAUNCH_VOTE_WIDE(P_MESH_ROOM); } else { LAUNCH_VOTE_WIDE(P_MESH); }
 #undef LAUNCH_VOTE_WIDE
@@ -671,6 +678,26 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
           ds->nodes4 = dptr;
         }
         if (wd) fprintf(stderr, "[rtx] RTX_WIDE: 4-wide tree %s (%d stack levels)\n", ds->nodes4 ? "on" : "off", ds->wide_levels);
+        if (getenv("RTX_VALIDATE")) {  // walk every wide tree on the host: codes in range, stack use within wide_levels
+          for (const rt::FlatEntry& e : fs.entries) {
+            if (e.kind != rt::ENTRY_BVH) continue;
+            std::vector<std::pair<int32_t, int>> todo;  // (code, stack entries below it)
+            todo.push_back({e.a, 0});
+            size_t visited = 0, bad = 0; int deepest = 0;
+            while (!todo.empty()) {
+              auto [code, below] = todo.back(); todo.pop_back();
+              if (code < 0) { if (rt::leaf_first(code) + rt::leaf_count(code) > (uint32_t)e.c) ++bad; continue; }
+              if ((size_t)code >= wide.size()) { ++bad; continue; }
+              ++visited;
+              int nk = 0;
+              for (int k = 0; k < 4; ++k) if (wide[code].child[k] != 0x7fffffff) ++nk;
+              deepest = std::max(deepest, below + nk);
+              for (int k = 0; k < 4; ++k) if (wide[code].child[k] != 0x7fffffff) todo.push_back({wide[code].child[k], below + nk - 1});
+            }
+            fprintf(stderr, "[rtx] RTX_VALIDATE: BVH root %d refs %d: %zu wide nodes walked, %zu bad codes, deepest stack %d of %d levels, sizeof(real) %zu\n",
+                    e.a, e.c, visited, bad, deepest, ds->wide_levels, sizeof(rt::real));
+          }
+        }
       }
     }
     {

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <utility>
 #include <string>
 #include <vector>
 #include <cstddef>

@@ -15,22 +15,30 @@ CASES = [
     ("dragon", rtsr.SCENE_STANFORD_DRAGON, 16.0 / 9.0, 480, 64),
     ("moving", rtsr.SCENE_RANDOM_MOVING, 16.0 / 9.0, 320, 64),
 ]
-only = sys.argv[1:]
+import os
+only = [a for a in sys.argv[1:] if not a.startswith("-")]
+F32_ONLY = "--f32-only" in sys.argv
+TINY = "--tiny" in sys.argv
 for name, sid, aspect, width, spp in CASES:
     if only and name not in only:
         continue
     b = rtsr.Builder(1)
     world, cam, bg = b.get_world_cam(sid)
     flat = b.flatten(world)
+    if TINY:
+        width, spp = 32, 1
     cfg = rtsr.Config.new(aspect, width, spp, 50, 10, seed=1, background=bg)
     out = {}
-    for mode in (False, True):
+    for mode in ((True,) if F32_ONLY else (False, True)):
         scene = flat.upload(f32=mode)
         scene.render_device(cam, cfg, want_stats=True)
         st = scene.render_device(cam, cfg, want_stats=True)
         img = scene.render(cam, cfg).accum / spp
         out[mode] = (img, st.trace_ms, rtsr.trace_kernel_name(st.trace_kernel))
         del scene
+    if F32_ONLY:
+        print("%-10s f32 only: kernel %s %.2f ms mean %.5f" % (name, out[True][2], out[True][1], out[True][0].mean()), flush=True)
+        continue
     a, b32 = out[False][0], out[True][0]
     la, lb = a.mean(axis=2), b32.mean(axis=2)
     close = np.abs(la - lb) <= 0.02 * (np.abs(la) + 0.02)
