@@ -487,11 +487,20 @@ def main():
             scenes.clear()
             del scene  # free C2's sample buffers first
             torch.cuda.empty_cache()
-            for name, x_spp, x_steps in (("head", 0, 3), ("c3", 256, 2), ("c4", 0, 2), ("c5", 120, 1)):
+            # "<name>_f32": the same workload through the statistical fast mode (rtx_scene_upload_f32) -- reported beside the
+            # f64 numbers, never instead of them: `value` and `dtype` of this line are the bit-exact f64 path
+            built = {}
+            for name, x_spp, x_steps in (("c2_f32", 0, 3), ("head", 0, 3), ("head_f32", 0, 3), ("c3", 256, 2), ("c3_f32", 256, 2),
+                                         ("c4", 0, 2), ("c4_f32", 0, 2), ("c5", 120, 1)):
                 try:
-                    xw = build_workload(rtsr, name, x_spp)
+                    f32 = name.endswith("_f32")
+                    wl = name[:-4] if f32 else name
+                    if wl not in built:
+                        built.clear()  # one flattened scene alive at a time (the dragon room is 0.3 GB of host arrays)
+                        built[wl] = build_workload(rtsr, wl, x_spp)
+                    xw = built[wl]
                     t_up = time.perf_counter()
-                    xs = xw["flat"].upload()
+                    xs = xw["flat"].upload(f32=f32)
                     t_up = time.perf_counter() - t_up
                     xs.render_device(xw["cam"], xw["cfg"], stream=stream, want_stats=True)  # warm-up
                     torch.cuda.synchronize()
@@ -506,7 +515,7 @@ def main():
                     extras[name] = {"workload": xw["desc"] + ("" if x_spp == 0 else " -- run at %d spp" % x_spp),
                                     "value": round(xw["width"] * xw["height"] * xw["spp"] / dt / 1e6, 1), "unit": "Msamples/s",
                                     "ms_per_step": round(dt * 1e3, 2), "trace_ms": round(ms / x_steps, 2), "kernel": rtsr.trace_kernel_name(kern),
-                                    "flatten_s": round(xw["flatten_s"], 2), "upload_s": round(t_up, 2)}
+                                    "flatten_s": round(xw["flatten_s"], 2), "upload_s": round(t_up, 2), "dtype": "f32 (statistical fast mode)" if f32 else "f64"}
                     del xs
                 except Exception as e:  # noqa: BLE001
                     extras[name] = {"error": repr(e)[:200]}
