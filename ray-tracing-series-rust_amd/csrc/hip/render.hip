@@ -472,7 +472,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         if (ds->world_diag && book2 && wide) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<P_BOOK2, true, 3, true>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream,
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<P_BOOK2, true, WORLD_WPS, true>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream,
                              ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries,
                              ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles,
                              ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->diag);
@@ -484,11 +484,11 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
             fprintf(stderr, "[world_diag] %-18s executions %llu lanes %llu mean lanes %.2f\n", names[k], hd[2 * k], hd[2 * k + 1],
                     hd[2 * k] ? (double)hd[2 * k + 1] / (double)hd[2 * k] : 0.0);
         } else if (has_gravity) {  // the bouncing-ball scene: the instantiation that carries GravitySphere code
-          if (wide) { LAUNCH_WORLD(P_ALL, true, 3); } else { LAUNCH_WORLD(P_ALL, false, 3); }
+          if (wide) { LAUNCH_WORLD(P_ALL, true, WORLD_WPS); } else { LAUNCH_WORLD(P_ALL, false, WORLD_WPS); }
         } else if (book2) {
-          if (wide) { LAUNCH_WORLD(P_BOOK2, true, 3); } else { LAUNCH_WORLD(P_BOOK2, false, 3); }
+          if (wide) { LAUNCH_WORLD(P_BOOK2, true, WORLD_WPS); } else { LAUNCH_WORLD(P_BOOK2, false, WORLD_WPS); }
         } else {
-          if (wide) { LAUNCH_WORLD(P_ANY, true, 3); } else { LAUNCH_WORLD(P_ANY, false, 3); }
+          if (wide) { LAUNCH_WORLD(P_ANY, true, WORLD_WPS); } else { LAUNCH_WORLD(P_ANY, false, WORLD_WPS); }
         }
 #undef LAUNCH_WORLD
       } else {
@@ -715,8 +715,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         if (wl > 64 * 1024) continue;
         int n = 0;
 #define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
-        if (wd) { WORLD_OCC(P_BOOK2, true, 3, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, 3, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, 3, ds->world_blocks_per_cu[2][1]); }
-        else { WORLD_OCC(P_BOOK2, false, 3, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ANY, false, 3, ds->world_blocks_per_cu[1][0]); WORLD_OCC(P_ALL, false, 3, ds->world_blocks_per_cu[2][0]); }
+        if (wd) { WORLD_OCC(P_BOOK2, true, WORLD_WPS, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, WORLD_WPS, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, WORLD_WPS, ds->world_blocks_per_cu[2][1]); }
+        else { WORLD_OCC(P_BOOK2, false, WORLD_WPS, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ANY, false, WORLD_WPS, ds->world_blocks_per_cu[1][0]); WORLD_OCC(P_ALL, false, WORLD_WPS, ds->world_blocks_per_cu[2][0]); }
 #undef WORLD_OCC
       }
     }
