@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline then reports no VALU fraction)")
     ap.add_argument("--keep-pmc", default="", help="directory to keep the raw counter CSVs in")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--shard-of", type=int, default=0, help="analysis only (N = 1): render just rank 0's shard of an N-GPU job per step; "
+                    "`value` is then N x this GPU's rate = what N GPUs would deliver before the gather")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="SAH bin count override (0 = library default)")
@@ -340,8 +342,11 @@ def main():
     n_cu = torch.cuda.get_device_properties(device_index).multi_processor_count
 
     shard = (rank, world_size, 1)  # rows j with j % N == rank
+    emulated = args.shard_of if (world_size == 1 and args.shard_of > 1) else 0
+    if emulated:
+        shard = (0, emulated, 1)
     my_rows = rtsr.shard_rows(cfg, shard)
-    max_rows = max(rtsr.shard_rows(cfg, (r, world_size, 1)) for r in range(world_size))
+    max_rows = max(rtsr.shard_rows(cfg, (r, shard[1], 1)) for r in range(shard[1]))
     # Frames are pipelined two deep: consecutive steps alternate between two resident copies of the scene (each owns its
     # render workspace), two streams and two output buffers, so the tail of frame k -- its few 50-bounce paths in otherwise idle
     # waves, the ordered reduction, the tone map and (N > 1) the gather -- overlaps the start of frame k + 1.  Nothing is skipped:
@@ -419,7 +424,7 @@ def main():
         img = np.zeros((height, width, 3), dtype=np.uint8)
         parts = gather_list if world_size > 1 else [d_rgb8]
         for r in range(world_size):
-            rows = list(range(r, height, world_size))
+            rows = list(range(r, height, shard[1]))
             img[rows] = parts[r].cpu().numpy()[: len(rows) * width * 3].reshape(len(rows), width, 3)
         if os.environ.get("BENCH_WRITE_PPM"):
             rtsr.Screen(width, height, img).write_to_ppm_file(os.environ["BENCH_WRITE_PPM"])
@@ -561,6 +566,9 @@ def main():
         }
         if extras is not None:
             out["other_workloads"] = extras
+        if emulated:
+            out["emulated_ranks"] = emulated
+            out["note"] = "analysis run: one GPU rendered rank 0's shard of a %d-GPU job; value = %d x its rate, no gather" % (emulated, emulated)
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

@@ -80,6 +80,7 @@ struct DeviceScene {
   int32_t vote_tri_base = -1;         // >= 0: that BVH is a pure triangle mesh whose slot s is triangle vote_tri_base + s
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 18;       // RTX_WALK_THRESHOLD (1 = never carry a walk over); 18 measured best on C2 (12..22 within 1 %)
+  uint32_t regen_min = 1;             // wide k_trace_vote: lanes that must be waiting before the wave regenerates (RTX_REGEN_MIN)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
@@ -409,7 +410,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
 #define LAUNCH_VOTE_WIDE(FEAT)                                                                         \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,  \
-                     (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels, \
+                     (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold | (ds->regen_min << 16), (uint32_t)ds->wide_levels, \
                      (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base)
           // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
           if (ds->vote_diag && (feat & ~P_MESH_ROOM) == 0) {
@@ -808,8 +809,10 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
           if (nd.child[ch] < 0) max_count = std::max(max_count, rt::leaf_count(nd.child[ch]));
       ds->leaf_weight = max_count <= 1 ? 1u : 3u;
       // latency-bound wide walks: measured best on the dragon room (639 vs 575 Msamples/s)
-      if (ds->nodes4) { ds->leaf_weight = 1u; ds->walk_threshold = 24u; }
+      if (ds->nodes4) { ds->leaf_weight = 1u; ds->walk_threshold = 24u; ds->regen_min = 8u; }  // regeneration waits for 8 lanes: 803 -> 824 on C4 (4: 817, 16: 801)
     }
+    const char* rm = getenv("RTX_REGEN_MIN");
+    if (rm && atoi(rm) >= 1 && atoi(rm) <= 64) ds->regen_min = (uint32_t)atoi(rm);
     const char* lw = getenv("RTX_LEAF_WEIGHT");
     if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
     const char* wt = getenv("RTX_WALK_THRESHOLD");
