@@ -119,6 +119,38 @@ RT_HD bool sphere_root(Point3 center, real radius, const Ray& r, real t_min, rea
   return true;
 }
 
+// sphere_root in two halves, for callers that ask the same sphere about the same ray more than once (a ConstantMedium asks
+// its boundary twice, hit.rs:961-967, and Book-2 lists each boundary sphere a third time as a glass ball of its own): the
+// quadratic is solved once and every query picks from the two roots exactly as sphere_root would -- same expressions on
+// the same operands, so the same bits.
+// *guard: what sphere_root adds to a query's t_min (0 in double precision; the fast mode's root uncertainty).
+RT_HD bool sphere_roots(Point3 center, real radius, const Ray& r, real* root1, real* root2, real* guard) {
+  Vec3 oc = r.origin - center;
+  real a = length_squared(r.direction);
+  real half_b = dot(oc, r.direction);
+  real c = length_squared(oc) - radius * radius;
+  real discriminant = half_b * half_b - a * c;
+  if (discriminant < real(0.0)) return false;
+#if defined(RT_F32)
+  *guard = real(0x1.0p-22) * (length_squared(oc) + radius * radius) / rt_fabs(half_b);
+#else
+  *guard = real(0.0);
+#endif
+  real sqrtd = rt_sqrt(discriminant);
+  *root1 = (-half_b - sqrtd) / a;
+  *root2 = (-half_b + sqrtd) / a;
+  return true;
+}
+RT_HD bool sphere_pick(real root1, real root2, real t_min, real t_max, real* t_out) {
+  real root = root1;
+  if (root < t_min || t_max < root) {
+    root = root2;
+    if (root < t_min || t_max < root) return false;
+  }
+  *t_out = root;
+  return true;
+}
+
 // hit.rs:111-149: plane hit, range test, three inside-edge tests.
 RT_HD bool triangle_t(const FlatTriangle& tr, const Ray& r, real t_min, real t_max,
                       real* t_out) {

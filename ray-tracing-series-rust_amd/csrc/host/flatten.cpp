@@ -399,7 +399,11 @@ struct Flattener {
       else if (e.kind == rt::ENTRY_GROUP) f |= rt::F_GROUP;
       else if (e.kind == rt::ENTRY_BVH) f |= rt::F_BVH;
       else if (e.kind == rt::ENTRY_XFORM) f |= rt::F_XFORM;
-      else if (e.kind == rt::ENTRY_MEDIUM) f |= rt::F_MEDIUM;
+      else if (e.kind == rt::ENTRY_MEDIUM) {
+        f |= rt::F_MEDIUM;
+        const rt::FlatEntry& boundary = out.entries[e.a];
+        if (!(boundary.kind == rt::ENTRY_PRIM && rt::primref_type((rt::PrimRef)boundary.a) == rt::PRIM_SPHERE)) f |= rt::F_MEDIUM_GENERAL;
+      }
     }
     for (const rt::FlatMaterial& m : out.materials) {
       if (m.kind == rt::MAT_LAMBERTIAN) f |= rt::F_LAMBERTIAN;
