@@ -21,7 +21,7 @@
  * render workspace (sample buffer, accumulators, work counter, timers): at most ONE render call may be in flight per
  * rtx_scene at a time -- calls on one handle must come from one thread at a time and, for rtx_render_device, on one
  * stream; concurrent renders of the same scene need one rtx_scene each (rtx_scene_upload is cheap next to a render).
- * The workspace is kept until rtx_scene_destroy or rtx_scene_trim (default budget of the sample buffer: 6 GiB).
+ * The workspace is kept until rtx_scene_destroy or rtx_scene_trim (default budget of the sample buffer: 24 GiB).
  */
 #ifndef RTX_ABI_H
 #define RTX_ABI_H

@@ -120,7 +120,7 @@ def test_c5_frame_shards_and_full_spp_rows(rtsr, orc):
         assert np.array_equal(acc, ref_accum), j
         assert np.array_equal(rgb, ref_rgb8), j
     # (c) the pass loop at full spp: 8 rows, sample buffer capped so that the 2000 samples take 67 passes (as a whole C5
-    # frame does with the default 6 GiB buffer: 30 spp per pass)
+    # frame does with a 6 GiB buffer: 30 spp per pass; the default, 24 GiB, takes 16)
     cfg_pass = rtsr.RtxConfig.from_buffer_copy(cfg_full)
     cfg_pass.sample_buffer_bytes = 8 * 3840 * 24 * 30
     band = (1, 270, 1)  # rows 1, 271, ... : 8 rows
