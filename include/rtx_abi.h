@@ -183,8 +183,8 @@ rtx_status rtx_scene_upload(const rtx_flat* f, rtx_scene** out);
 /* The statistical fast mode.  The same scene, narrowed field by field to single precision, rendered by
  * the same kernels compiled with float arithmetic (csrc/hip/render_f32.hip): the image converges to the same picture
  * but is NOT bit-comparable with the reference's -- the bit-exactness this header promises elsewhere is about scenes
- * uploaded with rtx_scene_upload.  Every render entry point takes either kind of scene; rtx_render_count and
- * rtx_multi_* are f64 only.  The RNG stream per (pixel, sample), the sample order of the sums and the f64 accumulators
+ * uploaded with rtx_scene_upload.  Every render entry point takes either kind of scene (rtx_multi_create_f32 for
+ * several GPUs); rtx_render_count is f64 only.  The RNG stream per (pixel, sample), the sample order of the sums and the f64 accumulators
  * handed back are the same in both modes. */
 rtx_status rtx_scene_upload_f32(const rtx_flat* f, rtx_scene** out);
 int32_t rtx_scene_is_f32(const rtx_scene* s);
@@ -257,6 +257,9 @@ typedef struct RtxMultiStats {
 } RtxMultiStats;
 rtx_status rtx_multi_create(const rtx_flat* f, int32_t n_shards, const int32_t* device_ids, int32_t block_rows,
                             rtx_multi** out);
+/* The same with every shard's scene uploaded by rtx_scene_upload_f32 (the statistical fast mode). */
+rtx_status rtx_multi_create_f32(const rtx_flat* f, int32_t n_shards, const int32_t* device_ids, int32_t block_rows,
+                                rtx_multi** out);
 void rtx_multi_destroy(rtx_multi* m); /* NULL-safe */
 /* Blocking.  out->rgb8 and / or out->accum_rgb: host buffers of h*w*3 elements (row 0 = bottom row). stats may be NULL. */
 rtx_status rtx_multi_render(rtx_multi* m, const RtxCamera* cam, const RtxConfig* cfg, RtxFrame* out, RtxMultiStats* stats);

@@ -129,6 +129,7 @@ ABI = {
     "rtx_flat_top_level_kind": (C.c_int32, [_VP, C.c_int32]),
     "rtx_scene_trim": (C.c_int32, [_VP]),
     "rtx_multi_create": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_VP)]),
+    "rtx_multi_create_f32": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_VP)]),
     "rtx_multi_destroy": (None, [_VP]),
     "rtx_multi_render": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.POINTER(RtxFrame), C.POINTER(RtxMultiStats)]),
     "rtx_render_multi": (C.c_int32, [_VP, C.POINTER(RtxCamera), C.POINTER(RtxConfig), C.c_int32, C.POINTER(RtxFrame)]),
@@ -452,10 +453,10 @@ class Scene:
 class MultiScene:
     """The scene resident on several GPUs of this process (rtx_multi): row-interleaved shards, one RCCL gather."""
 
-    def __init__(self, flat, n_shards, device_ids=None, block_rows=1):
+    def __init__(self, flat, n_shards, device_ids=None, block_rows=1, f32=False):
         ids = (C.c_int32 * n_shards)(*device_ids) if device_ids is not None else None
         p = _VP()
-        _check(lib.rtx_multi_create(flat.ptr, n_shards, ids, block_rows, C.byref(p)))
+        _check((lib.rtx_multi_create_f32 if f32 else lib.rtx_multi_create)(flat.ptr, n_shards, ids, block_rows, C.byref(p)))
         self._p = p
 
     def __del__(self):

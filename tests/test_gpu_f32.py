@@ -84,6 +84,18 @@ def test_f32_is_deterministic_and_shards_like_f64(rtsr):
     assert whole.shape[0] == h and np.array_equal(whole, one.accum)
 
 
+def test_f32_on_several_shards(rtsr):
+    """rtx_multi_create_f32: the frame cut into 3 row-interleaved shards (rehearsed on one GPU) equals the unsharded f32 frame."""
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(rtsr.SCENE_BOOK1_CANONICAL)
+    flat = b.flatten(world)
+    cfg = rtsr.Config.new(1.5, 90, 8, 50, 10, seed=2, background=bg)
+    whole = flat.upload(f32=True).render(cam, cfg)
+    parts = rtsr.MultiScene(flat, 3, device_ids=[0, 0, 0], f32=True).render(cam, cfg)
+    assert np.array_equal(parts.accum, whole.accum) and np.array_equal(parts.rgb8, whole.rgb8)
+    assert not np.array_equal(whole.accum, flat.upload().render(cam, cfg).accum)   # and it really is the other arithmetic
+
+
 def test_f32_handle_contract(rtsr):
     b = rtsr.Builder(1)
     world, cam, bg = b.get_world_cam(rtsr.SCENE_TRIANGLE_TEST)
