@@ -203,7 +203,8 @@ enum Feature : uint32_t {
   F_CHECKER = 1u << 14, F_NOISE = 1u << 15, F_IMAGE = 1u << 16,
   F_GRAVITY_SPHERE = 1u << 17,
   F_MEDIUM_GENERAL = 1u << 18,  // a medium whose boundary is anything but one plain static sphere (a box, a BVH, a moved object)
-  F_ALL = (1u << 19) - 1u,
+  F_MEDIUM_SPHERE = 1u << 19,   // a medium whose boundary is one plain static sphere (Book-2's smoke ball and fog)
+  F_ALL = (1u << 20) - 1u,
 };
 
 // Work counters for the algorithmic-bytes model.

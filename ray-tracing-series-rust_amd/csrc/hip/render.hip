@@ -95,7 +95,7 @@ struct DeviceScene {
   bool force_world = false;           // RTX_TRACE_KERNEL=world: k_trace_world even where a more special kernel applies (A/B)
   bool world_diag = false;            // RTX_TRACE_KERNEL=world_diag: region counters of k_trace_world on stderr (never timed)
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
-  int world_blocks_per_cu[3][2] = {{1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres][binary / wide]
+  int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
 };
 
@@ -460,10 +460,11 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         const bool wide = ds->nodes4 != nullptr;
         const bool book2 = (feat & ~P_BOOK2) == 0;
         const bool has_gravity = (feat & rt::F_GRAVITY_SPHERE) != 0;
+        const bool no_sphere_media = (feat & rt::F_MEDIUM_SPHERE) == 0;
         const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
         const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
-        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : 1)][wide ? 1 : 0];
+        uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : (no_sphere_media ? 3 : 1))][wide ? 1 : 0];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
 #define LAUNCH_WORLD(FEAT, WIDEF, WPS)                                                                   \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<FEAT, WIDEF, WPS>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream, \
@@ -488,6 +489,8 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
           if (wide) { LAUNCH_WORLD(P_ALL, true, WORLD_WPS); } else { LAUNCH_WORLD(P_ALL, false, WORLD_WPS); }
         } else if (book2) {
           if (wide) { LAUNCH_WORLD(P_BOOK2, true, WORLD_WPS); } else { LAUNCH_WORLD(P_BOOK2, false, WORLD_WPS); }
+        } else if (no_sphere_media) {
+          if (wide) { LAUNCH_WORLD(P_NO_SPHERE_MEDIA, true, WORLD_WPS); } else { LAUNCH_WORLD(P_NO_SPHERE_MEDIA, false, WORLD_WPS); }
         } else {
           if (wide) { LAUNCH_WORLD(P_ANY, true, WORLD_WPS); } else { LAUNCH_WORLD(P_ANY, false, WORLD_WPS); }
         }
@@ -716,8 +719,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         if (wl > 64 * 1024) continue;
         int n = 0;
 #define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
-        if (wd) { WORLD_OCC(P_BOOK2, true, WORLD_WPS, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, WORLD_WPS, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, WORLD_WPS, ds->world_blocks_per_cu[2][1]); }
-        else { WORLD_OCC(P_BOOK2, false, WORLD_WPS, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ANY, false, WORLD_WPS, ds->world_blocks_per_cu[1][0]); WORLD_OCC(P_ALL, false, WORLD_WPS, ds->world_blocks_per_cu[2][0]); }
+        if (wd) { WORLD_OCC(P_BOOK2, true, WORLD_WPS, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, WORLD_WPS, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, WORLD_WPS, ds->world_blocks_per_cu[2][1]); WORLD_OCC(P_NO_SPHERE_MEDIA, true, WORLD_WPS, ds->world_blocks_per_cu[3][1]); }
+        else { WORLD_OCC(P_BOOK2, false, WORLD_WPS, ds->world_blocks_per_cu[0][0]); WORLD_OCC(P_ANY, false, WORLD_WPS, ds->world_blocks_per_cu[1][0]); WORLD_OCC(P_ALL, false, WORLD_WPS, ds->world_blocks_per_cu[2][0]); WORLD_OCC(P_NO_SPHERE_MEDIA, false, WORLD_WPS, ds->world_blocks_per_cu[3][0]); }
 #undef WORLD_OCC
       }
     }

@@ -402,7 +402,8 @@ struct Flattener {
       else if (e.kind == rt::ENTRY_MEDIUM) {
         f |= rt::F_MEDIUM;
         const rt::FlatEntry& boundary = out.entries[e.a];
-        if (!(boundary.kind == rt::ENTRY_PRIM && rt::primref_type((rt::PrimRef)boundary.a) == rt::PRIM_SPHERE)) f |= rt::F_MEDIUM_GENERAL;
+        if (boundary.kind == rt::ENTRY_PRIM && rt::primref_type((rt::PrimRef)boundary.a) == rt::PRIM_SPHERE) f |= rt::F_MEDIUM_SPHERE;
+        else f |= rt::F_MEDIUM_GENERAL;
       }
     }
     for (const rt::FlatMaterial& m : out.materials) {
