@@ -217,7 +217,8 @@ enum {
   RTX_KERNEL_VOTE = 3,       /* worlds that are one BVH: node/leaf voting walk, f32 culling, carry-over */
   RTX_KERNEL_LDS = 4,        /* RTX_KERNEL_VOTE with the geometry resident in LDS (sphere worlds that fit) */
   RTX_KERNEL_WQ = 5,         /* experimental (not in the default build): workgroup-level path queues in LDS */
-  RTX_KERNEL_WORLD = 6       /* any world: per-lane scan of the world list, walks of every BVH entry carried over */
+  RTX_KERNEL_WORLD = 6,      /* any world: per-lane scan of the world list, walks of every BVH entry carried over */
+  RTX_KERNEL_WAVEFRONT = 7   /* split-kernel integrator: path state in HBM, k_wf_generate / k_wf_trace / k_wf_shade per bounce */
 };
 const char* rtx_trace_kernel_name(int32_t kernel);
 /* Blocking; host output buffers.  Renders the whole image on the current device. */

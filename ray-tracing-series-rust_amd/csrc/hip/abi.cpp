@@ -36,6 +36,7 @@ const char* rtx_trace_kernel_name(int32_t kernel) {
     case RTX_KERNEL_LDS: return "k_trace_lds";
     case RTX_KERNEL_WQ: return "k_trace_wq";
     case RTX_KERNEL_WORLD: return "k_trace_world";
+    case RTX_KERNEL_WAVEFRONT: return "k_wf_trace";
     default: return "?";
   }
 }

@@ -97,6 +97,20 @@ struct DeviceScene {
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
+  // wavefront integrator (trace_wave.inc): path pool in HBM, grown on demand by render calls
+  bool wave_ok = false;               // world == one BVH + plain primitive entries, sphere / mesh preset
+  bool force_wave = false;            // RTX_TRACE_KERNEL=wavefront
+  bool wave_default = false;          // the launcher prefers it for this scene (set at upload)
+  uint32_t wave_paths = 1u << 22;     // RTX_WF_PATHS: path slots P
+  uint32_t wave_refill = 16;          // RTX_WF_REFILL: free lanes a wave waits for before it takes new slots
+  uint32_t wave_check = 8;            // RTX_WF_CHECK: iterations between two looks at the counters
+  void* wave_mem = nullptr;
+  size_t wave_bytes = 0;
+  uint32_t* wave_host_ctrl = nullptr; // pinned
+  int wave_blocks_per_cu = 1;
+  int wave_iterations = 0;            // of the last render (diagnostics)
+  int wave_occ = 4;                   // RTX_WF_OCC: 256-thread blocks per CU k_wf_trace is compiled for (4 / 5 / 6; mesh room)
+  bool wave_verbose = false;          // RTX_WF_VERBOSE
 };
 
 #define HIP_TRY(expr)                                                                      \
@@ -131,6 +145,8 @@ static void free_device_scene(DeviceScene* ds) {
   if (ds->work_counter) (void)hipFree(ds->work_counter);
   if (ds->diag) (void)hipFree(ds->diag);
   if (ds->error_word) (void)hipFree(ds->error_word);
+  if (ds->wave_mem) (void)hipFree(ds->wave_mem);
+  if (ds->wave_host_ctrl) (void)hipHostFree(ds->wave_host_ctrl);
   for (int i = 0; i < 2; ++i)
     if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
   delete ds;
@@ -191,6 +207,7 @@ __device__ __forceinline__ void flush_counters(const rt::TraceCounters& c, rt::T
 #include "trace_wq.inc"      // k_trace_wq: measured dead end kept for A/B (build with -DRTX_EXPERIMENTAL_KERNELS)
 #endif
 #include "trace_lds.inc"     // k_trace_lds (the headline kernel)
+#include "trace_wave.inc"    // k_wf_generate / k_wf_trace / k_wf_shade: the split-kernel integrator (path state in HBM)
 #include "post_kernels.inc"  // k_reduce_samples, k_tonemap, device self tests
 
 // ------------------------------------------------------------------ launcher
@@ -231,6 +248,95 @@ static rt::RenderParams make_params(const RtxCamera* cam, const RtxConfig* cfg) 
   rp.max_depth = cfg->max_depth;
   rp.seed = cfg->seed;
   return rp;
+}
+
+// One pass (s_count samples of every pixel of the shard) through the wavefront integrator: iterations of
+// generate -> trace -> shade over the P path slots until every sample of the pass has been written.
+static rtx_status wave_pass(DeviceScene* ds, const rt::RenderParams& rp, const ShardMap& sm, uint32_t s_begin, uint32_t total,
+                            uint32_t npix, hipStream_t stream, int preset, uint32_t feat) {
+  uint32_t P = ds->wave_paths;
+  if ((uint64_t)P > (uint64_t)total) P = total;
+  P = (P + WF_SEG - 1u) & ~(WF_SEG - 1u);
+  const uint32_t n_seg = P / WF_SEG;
+  const size_t R = sizeof(rt::real);
+  const size_t bytes = 64 + (size_t)P * (16 + 7 * R + 3 * R + 3 * R + R + 4 + 4 + 4 + 4) + (size_t)n_seg * 8;
+  if (bytes > ds->wave_bytes) {
+    if (ds->wave_mem) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(ds->wave_mem)); ds->wave_mem = nullptr; ds->wave_bytes = 0; }
+    HIP_TRY(hipMalloc(&ds->wave_mem, bytes));
+    ds->wave_bytes = bytes;
+  }
+  if (!ds->wave_host_ctrl) HIP_TRY(hipHostMalloc((void**)&ds->wave_host_ctrl, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  WavePool pool;
+  {
+    unsigned char* m = (unsigned char*)ds->wave_mem;
+    pool.ctrl = (uint32_t*)m; m += 64;
+    pool.rng = (unsigned long long*)m; m += (size_t)P * 16;
+    pool.ray = (rt::real*)m; m += (size_t)P * 7 * R;
+    pool.product = (rt::real*)m; m += (size_t)P * 3 * R;
+    pool.output = (rt::real*)m; m += (size_t)P * 3 * R;
+    pool.hit_t = (rt::real*)m; m += (size_t)P * R;
+    pool.depth = (int32_t*)m; m += (size_t)P * 4;
+    pool.g = (uint32_t*)m; m += (size_t)P * 4;
+    pool.hit_ref = (uint32_t*)m; m += (size_t)P * 4;
+    pool.free_list = (uint32_t*)m; m += (size_t)P * 4;
+    pool.n_free = (uint32_t*)m; m += (size_t)n_seg * 4;
+    pool.cursor = (uint32_t*)m; m += (size_t)n_seg * 4;
+    pool.P = P;
+  }
+  const bool wide = preset == 1 && ds->nodes4 != nullptr;
+  const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : ds->view.max_stack + 1);
+  const size_t lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t);
+  if (lds > 64 * 1024) { set_error("render: BVH too deep for the LDS traversal stack"); return RTX_EUNSUPPORTED; }
+  const bool room = (feat & ~P_MESH_ROOM) == 0;
+  const int occ = ds->wave_occ;
+  const uint32_t leaf_weight = ds->leaf_weight, refill = ds->wave_refill, bvh_pos = (uint32_t)ds->vote_bvh_pos;
+  // every combination the launcher can ask for, once: (trace kernel, shade kernel) by preset / tree / occupancy target
+#define WF_CASES(X)                                                                                                          \
+  if (preset == 0) { X(P_SPHERES, false, 4); }                                                                               \
+  else if (!wide) { X(P_MESH, false, 4); }                                                                                   \
+  else if (room && occ == 5) { X(P_MESH_ROOM, true, 5); }                                                                    \
+  else if (room && occ == 6) { X(P_MESH_ROOM, true, 6); }                                                                    \
+  else if (room) { X(P_MESH_ROOM, true, 4); }                                                                                \
+  else { X(P_MESH, true, 4); }
+  int nb = 0;
+  hipError_t oe = hipSuccess;
+#define WF_OCC(FEAT, WIDEF, MB) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_wf_trace<FEAT, WIDEF, MB>, TRACE_BLOCK, lds)
+  WF_CASES(WF_OCC)
+#undef WF_OCC
+  if (oe != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 1; }
+  ds->wave_blocks_per_cu = nb;
+  const uint64_t want = ((uint64_t)P + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  const uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)nb;
+  const uint32_t tgrid = (uint32_t)(want < resident ? want : resident);
+  hipLaunchKernelGGL(k_wf_init, dim3((P + 255u) / 256u), dim3(256), 0, stream, pool);
+  uint32_t check_every = ds->wave_check;
+  int it = 0;
+  for (;; ++it) {
+    hipLaunchKernelGGL(k_wf_generate, dim3(n_seg), dim3(WF_SEG), 0, stream, pool, rp, sm, s_begin, total, npix);
+    if ((uint32_t)(it + 1) % check_every == 0u) {
+      HIP_TRY(hipMemsetAsync(pool.ctrl, 0, 16, stream));
+      hipLaunchKernelGGL(k_wf_count, dim3(256), dim3(256), 0, stream, pool);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(ds->wave_host_ctrl, pool.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      // no path alive after a generation: every segment's share of the pass is used up and every path has ended
+      if (ds->wave_host_ctrl[0] == 0u) break;
+      if (ds->wave_host_ctrl[0] < P / 2u) check_every = 2;  // the tail: the pool drains within max_depth iterations
+      if (it > 100000000) { set_error("render: wavefront integrator did not converge"); return RTX_EHIP; }
+    }
+#define WF_LAUNCH(FEAT, WIDEF, MB)                                                                                           \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<FEAT, WIDEF, MB>), dim3(tgrid), dim3(TRACE_BLOCK), lds, stream, ds->view, pool, \
+                       leaf_weight, refill, bvh_pos, ds->nodes4, ds->vote_tri_base);                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_shade<FEAT>), dim3(n_seg), dim3(WF_SEG), 0, stream, ds->view, pool, rp, ds->samples, bvh_pos); \
+  } while (0)
+    WF_CASES(WF_LAUNCH)
+#undef WF_LAUNCH
+  }
+#undef WF_CASES
+  ds->wave_iterations = it + 1;
+  if (ds->wave_verbose) fprintf(stderr, "[rtx] wavefront: %u slots, %d iterations, %d blocks per CU (%u stack levels)\n", P, it + 1, nb, levels);
+  return RTX_OK;
 }
 
 template <bool COUNT>
@@ -326,7 +432,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
           else { LAUNCH_SIMPLE(P_ALL); }
         }
 #undef LAUNCH_SIMPLE
-      } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream && !ds->force_world) {
+      } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream && !ds->force_world && !ds->force_wave) {
         kernel_used = RTX_KERNEL_LDS;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims);
@@ -376,6 +482,10 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         HIP_TRY(hipStreamSynchronize(stream));
         if (err != 0) { set_error("render: k_trace_wq aborted (bounded wait tripped, code " + std::to_string(err) + ")"); return RTX_EHIP; }
 #endif
+      } else if (ds->wave_ok && preset < 2 && (ds->force_wave || (ds->wave_default && !ds->force_vote && !ds->force_persistent && !ds->force_world && !ds->force_stream))) {
+        kernel_used = RTX_KERNEL_WAVEFRONT;
+        st = wave_pass(ds, rp, sm, s_begin, total, (uint32_t)npix, stream, preset, feat);
+        if (st != RTX_OK) return st;
       } else if (ds->vote_ok && preset < 2 && !ds->force_persistent && !ds->force_world && !(ds->force_stream && ds->single_bvh)) {
         kernel_used = RTX_KERNEL_VOTE;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
@@ -608,6 +718,18 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
     ds->world_diag = (k && strcmp(k, "world_diag") == 0);
     ds->force_world = ds->world_diag || (k && strcmp(k, "world") == 0);
     ds->force_vote = ds->vote_diag || (k && strcmp(k, "vote") == 0);
+    ds->force_wave = (k && strcmp(k, "wavefront") == 0);
+    {
+      const char* wp = getenv("RTX_WF_PATHS");
+      if (wp && atol(wp) >= 256 && atol(wp) <= (1l << 27)) ds->wave_paths = (uint32_t)atol(wp);
+      const char* wr = getenv("RTX_WF_REFILL");
+      if (wr && atoi(wr) >= 1 && atoi(wr) <= 64) ds->wave_refill = (uint32_t)atoi(wr);
+      const char* wo = getenv("RTX_WF_OCC");
+      if (wo && atoi(wo) >= 4 && atoi(wo) <= 6) ds->wave_occ = atoi(wo);
+      ds->wave_verbose = getenv("RTX_WF_VERBOSE") != nullptr;
+      const char* wc = getenv("RTX_WF_CHECK");
+      if (wc && atoi(wc) >= 1 && atoi(wc) <= 4096) ds->wave_check = (uint32_t)atoi(wc);
+    }
     {
       const size_t lds_ring = lds + (TRACE_BLOCK / 64) * RING_BYTES_PER_WAVE;
       int nb0 = 0, nb1 = 0;
@@ -636,6 +758,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         else if (kind != rt::ENTRY_PRIM) ++n_other;
       }
       ds->vote_ok = n_bvh == 1 && n_other == 0;
+      ds->wave_ok = ds->vote_ok;
       if (ds->vote_ok) {
         const rt::FlatEntry& be = fs.entries[fs.top_level[ds->vote_bvh_pos]];
         bool pure = be.c > 0 && rt::primref_type(fs.refs[be.b]) == rt::PRIM_TRIANGLE;

@@ -113,8 +113,8 @@ def test_no_cpu_fallback_without_gpu(rtsr):
 
 def test_trace_kernel_names(rtsr):
     """RtxRenderStats.trace_kernel ids map to the kernel names rocprofv3 prints."""
-    names = [rtsr.trace_kernel_name(k) for k in range(7)]
-    assert names == ["k_trace_simple", "k_trace_persistent", "k_trace_stream", "k_trace_vote", "k_trace_lds", "k_trace_wq", "k_trace_world"]
+    names = [rtsr.trace_kernel_name(k) for k in range(8)]
+    assert names == ["k_trace_simple", "k_trace_persistent", "k_trace_stream", "k_trace_vote", "k_trace_lds", "k_trace_wq", "k_trace_world", "k_wf_trace"]
     assert rtsr.trace_kernel_name(99) == "?"
     for n in names:  # every reported name is a kernel that exists in the sources
         assert any(n in open(os.path.join(ROOT, "ray-tracing-series-rust_amd", "csrc", "hip", f)).read()
