@@ -82,7 +82,11 @@ def main():
         light_rows[str(row)] = [run[0] + 90, run[1] + 90]
     regions = {"background_right_of_light": (60, 160, 720, 990), "background_right": (180, 280, 820, 990),
                "background_middle": (170, 250, 250, 480), "background_between_spheres": (420, 460, 240, 300),
-               "background_left": (160, 240, 0, 45), "background_far_right": (300, 600, 940, 1000)}
+               "background_left": (160, 240, 0, 45), "background_far_right": (300, 600, 940, 1000),
+               # objects whose place is fixed and whose randomness averages out inside the region: the moving sphere
+               # (MovingSphere, Lambertian (0.7, 0.3, 1), blurred over its 30 units of travel), the marble sphere (NoiseTexture 0.1:
+               # the permutation tables are random, the mean is not), the blue subsurface sphere (glass ball + ConstantMedium 0.2)
+               "moving_sphere": (290, 370, 90, 190), "marble_sphere": (430, 560, 380, 500), "subsurface_sphere": (650, 800, 200, 340)}
     pins["book2"] = {
         "width": 1000, "height": 1000, "black_top_rows": black,
         "light_rows": light_rows,
