@@ -15,7 +15,11 @@
 // Parity status: the reference (Rust, rand 0.8.5 OS-seeded) can be neither built nor run
 // here and its own tests (src/vec3.rs:343-428) pin only Vec3 algebra, so for the hot path
 // this oracle is pinned by (1) those 9 Vec3 tests, (2) hand-derived known-answer tests
-//  and (3) nothing else: "parity unpinned" against reference OUTPUT.
+//  and (3) the three images the reference ships (images/book1.png, book2.png,
+// stanford_dragon.png): silhouettes / wall edges / the light's outline to a pixel or two and the mean radiance
+// of regions its unseeded randomness does not shape to a few per cent (tests/test_reference_image_pins.py,
+// fixture + generator under tests/golden/).  No output of the reference can be reproduced bit for bit
+// (OS-seeded thread_rng): at the level of bits this oracle remains "parity unpinned".
 //
 // Each function cites the reference lines it follows (paths relative to /root/reference/src).
 #include <algorithm>

@@ -11,7 +11,8 @@
 // It also yields the exact work counters behind the algorithmic-bytes model.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
-// Parity status vs the reference's OUTPUT: unpinned (see o1_literal.cpp header).
+// Parity status vs the reference's OUTPUT: statistical pins against its three images, bit-level parity unpinned
+// (see o1_literal.cpp header).
 #include <algorithm>
 #include <cstring>
 #include <thread>
