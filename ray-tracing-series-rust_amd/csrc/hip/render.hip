@@ -97,6 +97,7 @@ struct DeviceScene {
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
+  uint32_t world_perlin_lds = 0;      // Perlin tables k_trace_world copies into LDS (RTX_PERLIN_LDS=0: none)
   // wavefront integrator (trace_wave.inc): path pool in HBM, grown on demand by render calls
   bool wave_ok = false;               // world == one BVH + plain primitive entries, sphere / mesh preset
   bool force_wave = false;            // RTX_TRACE_KERNEL=wavefront
@@ -572,7 +573,8 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         const bool has_gravity = (feat & rt::F_GRAVITY_SPHERE) != 0;
         const bool no_sphere_media = (feat & rt::F_MEDIUM_SPHERE) == 0;
         const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
-        const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
+        const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real) +
+                                 (size_t)ds->world_perlin_lds * sizeof(rt::FlatPerlin);
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : (no_sphere_media ? 3 : 1))][wide ? 1 : 0];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
@@ -580,14 +582,14 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<FEAT, WIDEF, WPS>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries, \
                      ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles, \
-                     ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels)
+                     ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds)
         if (ds->world_diag && book2 && wide) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<P_BOOK2, true, WORLD_WPS, true>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream,
                              ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries,
                              ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles,
-                             ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->diag);
+                             ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds, ds->diag);
           HIP_TRY(hipStreamSynchronize(stream));
           unsigned long long hd[16];
           HIP_TRY(hipMemcpy(hd, ds->diag, sizeof(hd), hipMemcpyDeviceToHost));
@@ -838,8 +840,17 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       if (wth && atoi(wth) >= 0 && atoi(wth) <= 64) ds->world_threshold = (uint32_t)atoi(wth);
       for (int wd = 0; wd < 2; ++wd) {
         const uint32_t levels = (uint32_t)(wd ? ds->wide_levels : fs.max_stack + 1);
-        const size_t wl = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
+        size_t wl = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real);
         if (wl > 64 * 1024) continue;
+        // Perlin tables in LDS when that costs no resident block (3 per CU at 168 VGPRs: up to 53 KB each)
+        if ((wd != 0) == (ds->nodes4 != nullptr)) {
+          const char* pl = getenv("RTX_PERLIN_LDS");
+          const size_t n_p = fs.perlins.size();
+          if (n_p >= 1 && n_p <= 2 && !(pl && atoi(pl) == 0) && wl + n_p * sizeof(rt::FlatPerlin) <= 52 * 1024) {
+            ds->world_perlin_lds = (uint32_t)n_p;
+            wl += n_p * sizeof(rt::FlatPerlin);
+          }
+        }
         int n = 0;
 #define WORLD_OCC(FEAT, WIDEF, WPS, OUT) if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_world<FEAT, WIDEF, WPS>, TRACE_BLOCK, wl) == hipSuccess && n > 0) OUT = n
         if (wd) { WORLD_OCC(P_BOOK2, true, WORLD_WPS, ds->world_blocks_per_cu[0][1]); WORLD_OCC(P_ANY, true, WORLD_WPS, ds->world_blocks_per_cu[1][1]); WORLD_OCC(P_ALL, true, WORLD_WPS, ds->world_blocks_per_cu[2][1]); WORLD_OCC(P_NO_SPHERE_MEDIA, true, WORLD_WPS, ds->world_blocks_per_cu[3][1]); }
