@@ -97,6 +97,7 @@ struct DeviceScene {
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
+  uint32_t world_mat_lds = 0, world_tex_lds = 0;  // material / texture records k_trace_world copies into LDS (RTX_MAT_LDS=0: none)
   uint32_t world_perlin_lds = 0;      // Perlin tables k_trace_world copies into LDS (RTX_PERLIN_LDS=0: none)
   // wavefront integrator (trace_wave.inc): path pool in HBM, grown on demand by render calls
   bool wave_ok = false;               // world == one BVH + plain primitive entries, sphere / mesh preset
@@ -574,7 +575,8 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         const bool no_sphere_media = (feat & rt::F_MEDIUM_SPHERE) == 0;
         const uint32_t levels = (uint32_t)(wide ? ds->wide_levels : stack_levels);
         const size_t world_lds = (size_t)levels * TRACE_BLOCK * sizeof(int32_t) + (size_t)WORLD_SLOT_F64 * TRACE_BLOCK * sizeof(rt::real) +
-                                 (size_t)ds->world_perlin_lds * sizeof(rt::FlatPerlin);
+                                 (size_t)ds->world_perlin_lds * sizeof(rt::FlatPerlin) +
+                                 (size_t)ds->world_mat_lds * sizeof(rt::FlatMaterial) + (size_t)ds->world_tex_lds * sizeof(rt::FlatTexture);
         uint64_t want = ((uint64_t)total + TRACE_BLOCK - 1) / TRACE_BLOCK;
         uint64_t resident = (uint64_t)ds->n_cu * (uint64_t)ds->world_blocks_per_cu[has_gravity ? 2 : (book2 ? 0 : (no_sphere_media ? 3 : 1))][wide ? 1 : 0];
         uint32_t grid = (uint32_t)(want < resident ? want : resident);
@@ -582,14 +584,14 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<FEAT, WIDEF, WPS>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries, \
                      ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles, \
-                     ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds)
+                     ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds, ds->world_mat_lds, ds->world_tex_lds)
         if (ds->world_diag && book2 && wide) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 24 * sizeof(unsigned long long), stream));
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_world<P_BOOK2, true, WORLD_WPS, true>), dim3(grid), dim3(TRACE_BLOCK), world_lds, stream,
                              ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter, ds->view.entries,
                              ds->view.top_level, ds->view.spheres, ds->view.moving_spheres, ds->view.rects, ds->view.triangles,
-                             ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds, ds->diag);
+                             ds->view.materials, ds->view.textures, ds->view.refs, ds->nodes4, ds->world_desc, ds->leaf_weight, ds->world_threshold, levels, ds->world_perlin_lds, ds->world_mat_lds, ds->world_tex_lds, ds->diag);
           HIP_TRY(hipStreamSynchronize(stream));
           unsigned long long hd[16];
           HIP_TRY(hipMemcpy(hd, ds->diag, sizeof(hd), hipMemcpyDeviceToHost));
@@ -849,6 +851,14 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
           if (n_p >= 1 && n_p <= 2 && !(pl && atoi(pl) == 0) && wl + n_p * sizeof(rt::FlatPerlin) <= 52 * 1024) {
             ds->world_perlin_lds = (uint32_t)n_p;
             wl += n_p * sizeof(rt::FlatPerlin);
+          }
+          const char* ml = getenv("RTX_MAT_LDS");
+          const size_t mt = fs.materials.size() * sizeof(rt::FlatMaterial) + fs.textures.size() * sizeof(rt::FlatTexture);
+          if (!fs.materials.empty() && !fs.textures.empty() && fs.materials.size() <= 64 && fs.textures.size() <= 64 && !(ml && atoi(ml) == 0) &&
+              wl + mt <= 52 * 1024) {
+            ds->world_mat_lds = (uint32_t)fs.materials.size();
+            ds->world_tex_lds = (uint32_t)fs.textures.size();
+            wl += mt;
           }
         }
         int n = 0;
