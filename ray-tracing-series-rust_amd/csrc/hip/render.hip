@@ -97,6 +97,8 @@ struct DeviceScene {
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
+  uint32_t vote_tables = 0;           // wide k_trace_vote: materials | textures << 16 to keep in LDS (0: none; RTX_MAT_LDS=0)
+  size_t vote_tables_bytes = 0;
   uint32_t world_mat_lds = 0, world_tex_lds = 0;  // material / texture records k_trace_world copies into LDS (RTX_MAT_LDS=0: none)
   uint32_t world_perlin_lds = 0;      // Perlin tables k_trace_world copies into LDS (RTX_PERLIN_LDS=0: none)
   // wavefront integrator (trace_wave.inc): path pool in HBM, grown on demand by render calls
@@ -501,7 +503,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF, false>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
                      ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos, \
-                     (const FlatNode4*)nullptr, ds->vote_tri_base)
+                     (const FlatNode4*)nullptr, ds->vote_tri_base, 0u)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
@@ -516,14 +518,20 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         }
         else if (preset == 0) { if (ring) { LAUNCH_VOTE(P_SPHERES, false, true, (unsigned long long*)nullptr); } else { LAUNCH_VOTE(P_SPHERES, false, false, (unsigned long long*)nullptr); } }
         else if (ds->nodes4) {
-          const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
+          // material / texture records behind the stacks when that costs no resident block
+          uint32_t lds_tables = 0;
+          size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
+          if (ds->vote_tables_bytes > 0 && (wide_lds + ds->vote_tables_bytes) * (size_t)ds->wide_blocks_per_cu <= 160 * 1024) {
+            lds_tables = ds->vote_tables;
+            wide_lds += ds->vote_tables_bytes;
+          }
           uint64_t res4 = (uint64_t)ds->n_cu * (uint64_t)ds->wide_blocks_per_cu;
           grid = (uint32_t)(want < res4 ? want : res4);
 #define LAUNCH_VOTE_WIDE(FEAT)                                                                         \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,  \
                      (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold | (ds->regen_min << 16), (uint32_t)ds->wide_levels, \
-                     (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base)
+                     (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables)
           // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
           if (ds->vote_diag && (feat & ~P_MESH_ROOM) == 0) {
             if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
@@ -531,7 +539,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH_ROOM, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
                                stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
                                ds->diag, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
-                               (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base);
+                               (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables);
             HIP_TRY(hipStreamSynchronize(stream));
             unsigned long long h[24];
             HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
@@ -829,6 +837,13 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
                     e.a, e.c, visited, bad, deepest, ds->wide_levels, sizeof(rt::real));
           }
         }
+      }
+    }
+    {
+      const char* ml = getenv("RTX_MAT_LDS");
+      if (!fs.materials.empty() && !fs.textures.empty() && fs.materials.size() <= 16 && fs.textures.size() <= 16 && !(ml && atoi(ml) == 0)) {
+        ds->vote_tables = (uint32_t)fs.materials.size() | ((uint32_t)fs.textures.size() << 16);
+        ds->vote_tables_bytes = fs.materials.size() * sizeof(rt::FlatMaterial) + fs.textures.size() * sizeof(rt::FlatTexture);
       }
     }
     {
