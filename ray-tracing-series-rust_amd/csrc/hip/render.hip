@@ -47,6 +47,20 @@ struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
   uint32_t n_nodes, n_refs, n_spheres, n_moving;
 };
 
+// The plain primitive entries beside the BVH in the world list (the dragon room's seven rectangles), as a kernel argument:
+// list position, primitive reference and -- when all of them are rectangles -- the records themselves, for up to 8 entries.
+// Read from the world list they cost three DEPENDENT scalar loads each, per ray (top_level[k] -> entries[..].a -> the
+// primitive record); from the kernarg segment a record is one load at base + i * stride.  n < 0: not applicable, the kernel
+// walks the list.  (Measured: the same loop fully unrolled over the 8 slots is 8 % SLOWER than the list walk -- eight copies
+// of the three-axis rectangle test do not fit the instruction cache next to the rest of the kernel.)
+struct VoteTop {
+  int32_t n;
+  int32_t all_rects;
+  int32_t k[8];
+  uint32_t ref[8];
+  rt::FlatRect rect[8];
+};
+
 struct DeviceScene {
   int device = -1;
   std::vector<void*> allocations;
@@ -97,6 +111,7 @@ struct DeviceScene {
   uint32_t world_threshold = 8;       // k_trace_world: walk steps have priority while this many lanes walk (RTX_WORLD_THRESHOLD; 0 = plain majority vote)
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
+  VoteTop vote_top;                   // the plain entries beside the BVH, for k_trace_vote's kernarg (n = -1: not applicable)
   uint32_t vote_tables = 0;           // wide k_trace_vote: materials | textures << 16 to keep in LDS (0: none; RTX_MAT_LDS=0)
   size_t vote_tables_bytes = 0;
   uint32_t world_mat_lds = 0, world_tex_lds = 0;  // material / texture records k_trace_world copies into LDS (RTX_MAT_LDS=0: none)
@@ -503,7 +518,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, DIAGF, RINGF, false>), dim3(grid), dim3(TRACE_BLOCK), vote_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples,            \
                      ds->work_counter, DIAGP, ds->leaf_weight, ds->walk_threshold, (uint32_t)stack_levels, (uint32_t)ds->vote_bvh_pos, \
-                     (const FlatNode4*)nullptr, ds->vote_tri_base, 0u)
+                     (const FlatNode4*)nullptr, ds->vote_tri_base, 0u, ds->vote_top)
         if (ds->vote_diag && preset == 0) {
           if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
           HIP_TRY(hipMemsetAsync(ds->diag, 0, 12 * sizeof(unsigned long long), stream));
@@ -531,7 +546,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<FEAT, false, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds, \
                      stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,  \
                      (unsigned long long*)nullptr, ds->leaf_weight, ds->walk_threshold | (ds->regen_min << 16), (uint32_t)ds->wide_levels, \
-                     (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables)
+                     (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables, ds->vote_top)
           // a triangle mesh in a room of rectangles, no spheres / lists / glass (the dragon room): the leaner instantiation
           if (ds->vote_diag && (feat & ~P_MESH_ROOM) == 0) {
             if (!ds->diag) HIP_TRY(hipMalloc((void**)&ds->diag, 24 * sizeof(unsigned long long)));
@@ -539,7 +554,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_vote<P_MESH_ROOM, true, false, true>), dim3(grid), dim3(TRACE_BLOCK), wide_lds,
                                stream, ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,
                                ds->diag, ds->leaf_weight, ds->walk_threshold, (uint32_t)ds->wide_levels,
-                               (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables);
+                               (uint32_t)ds->vote_bvh_pos, ds->nodes4, ds->vote_tri_base, lds_tables, ds->vote_top);
             HIP_TRY(hipStreamSynchronize(stream));
             unsigned long long h[24];
             HIP_TRY(hipMemcpy(h, ds->diag, sizeof(h), hipMemcpyDeviceToHost));
@@ -688,6 +703,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
   *out = nullptr;
   DeviceScene* ds = new (std::nothrow) DeviceScene();
   if (!ds) { set_error("out of memory"); return RTX_ENOMEM; }
+  memset(&ds->vote_top, 0, sizeof(ds->vote_top));
+  ds->vote_top.n = -1;
   hipError_t e = hipGetDevice(&ds->device);
   if (e != hipSuccess) {
     set_error(std::string("hipGetDevice: ") + hipGetErrorString(e) + " (this library has no CPU render path)");
@@ -770,6 +787,20 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         else if (kind != rt::ENTRY_PRIM) ++n_other;
       }
       ds->vote_ok = n_bvh == 1 && n_other == 0;
+      if (ds->vote_ok && fs.top_level.size() <= 9 && !(getenv("RTX_VOTE_TOP") && atoi(getenv("RTX_VOTE_TOP")) == 0)) {
+        ds->vote_top.n = 0;
+        ds->vote_top.all_rects = 1;
+        for (size_t k = 0; k < fs.top_level.size(); ++k) {
+          if ((int32_t)k == ds->vote_bvh_pos) continue;
+          const rt::PrimRef ref = (rt::PrimRef)fs.entries[fs.top_level[k]].a;
+          ds->vote_top.k[ds->vote_top.n] = (int32_t)k;
+          ds->vote_top.ref[ds->vote_top.n] = (uint32_t)ref;
+          if (rt::primref_type(ref) == rt::PRIM_RECT) ds->vote_top.rect[ds->vote_top.n] = fs.rects[rt::primref_index(ref)];
+          else ds->vote_top.all_rects = 0;
+          ds->vote_top.n += 1;
+        }
+        if (!ds->vote_top.all_rects) ds->vote_top.n = -1;
+      }
       ds->wave_ok = ds->vote_ok;
       if (ds->vote_ok) {
         const rt::FlatEntry& be = fs.entries[fs.top_level[ds->vote_bvh_pos]];
