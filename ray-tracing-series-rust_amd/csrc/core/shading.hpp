@@ -151,11 +151,19 @@ RT_HD real reflectance(real cosine, real ref_idx) {
 }
 
 // Material::emitted (hit.rs:1015-1017 default, 1149-1151 DiffuseLight).
+// Texture::value of a material's texture.  A scene without checker, noise and image textures has SolidColors only, and the
+// flattener has copied each one's colour into the material record: no second, dependent fetch.
+template <uint32_t F, bool COUNT>
+RT_HD Color material_texture_value(const SceneView& sv, const FlatMaterial& m, const HitRecord& rec, TraceCounters* cnt) {
+  if (!(F & (F_CHECKER | F_NOISE | F_IMAGE))) return load_v3(m.albedo);
+  return texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+}
+
 template <uint32_t F, bool COUNT>
 RT_HD Color material_emitted(const SceneView& sv, const FlatMaterial& m, const HitRecord& rec,
                              TraceCounters* cnt) {
   if ((F & F_LIGHT) && m.kind == MAT_DIFFUSE_LIGHT)
-    return texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+    return material_texture_value<F, COUNT>(sv, m, rec, cnt);
   return v3(0, 0, 0);
 }
 
@@ -178,7 +186,7 @@ RT_HD bool material_scatter_with_sample(const SceneView& sv, const FlatMaterial&
     Vec3 scatter_direction = rec.normal + unit(sphere_sample);  // random_unit_vector, vec3.rs:297-299
     if (near_zero(scatter_direction)) scatter_direction = rec.normal;
     *scattered = make_ray(rec.p, scatter_direction, r_in.time);
-    *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+    *attenuation = material_texture_value<F, COUNT>(sv, m, rec, cnt);
     return true;
   }
   if ((F & F_METAL) && m.kind == MAT_METAL) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
@@ -205,7 +213,7 @@ RT_HD bool material_scatter_with_sample(const SceneView& sv, const FlatMaterial&
   }
   if ((F & F_ISOTROPIC) && m.kind == MAT_ISOTROPIC) {  // hit.rs:1005-1010
     *scattered = make_ray(rec.p, sphere_sample, r_in.time);
-    *attenuation = texture_value<F, COUNT>(sv, m.tex, rec.u, rec.v, rec.p, cnt);
+    *attenuation = material_texture_value<F, COUNT>(sv, m, rec, cnt);
     return true;
   }
   return false;  // MAT_DIFFUSE_LIGHT, hit.rs:1146-1148

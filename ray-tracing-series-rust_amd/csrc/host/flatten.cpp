@@ -376,6 +376,13 @@ struct Flattener {
       f.albedo[0] = m.albedo[0]; f.albedo[1] = m.albedo[1]; f.albedo[2] = m.albedo[2];
       f.param = m.param;
       f.needs_uv = texture_has_image(m.tex) ? 1 : 0;
+      // SolidColor::value (texture.rs:27-31) resolved here: kernels compiled for scenes without checker / noise / image
+      // textures read the colour from the material record and never fetch the texture record behind it
+      if ((m.kind == rt::MAT_LAMBERTIAN || m.kind == rt::MAT_DIFFUSE_LIGHT || m.kind == rt::MAT_ISOTROPIC) && m.tex >= 0 &&
+          (size_t)m.tex < g.textures.size() && g.textures[m.tex].kind == rt::TEX_SOLID) {
+        const GTexture& t = g.textures[m.tex];
+        f.albedo[0] = t.color[0]; f.albedo[1] = t.color[1]; f.albedo[2] = t.color[2];
+      }
       out.materials.push_back(f);
     }
     out.perlins = g.perlins;
