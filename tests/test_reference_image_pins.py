@@ -36,6 +36,13 @@ def _linear_mean(radiance_top, box):
     return radiance_top[r0:r1, c0:c1].reshape(-1, 3).mean(axis=0)
 
 
+def _as_the_png_sees_it(radiance_top):
+    """A converged frame's radiance limited per pixel to what an 8-bit PNG value can express (vec3.rs:89-107 clamps
+    sqrt(radiance) to 0.999): regions with saturated pixels (the moving sphere's blue) are compared like with like.  Only for
+    high-spp frames -- clamping the noisy pixels of a 6-spp frame would bias bright regions."""
+    return np.minimum(radiance_top, (255.5 / 256.0) ** 2)
+
+
 def check_dragon(rgb_top, radiance_top, rel_tol, edge_tol=2):
     pin = PINS["stanford_dragon"]
     assert rgb_top.shape == (pin["height"], pin["width"], 3)
@@ -148,7 +155,7 @@ def test_gpu_dragon_room_against_reference_image(rtsr):
     screen = b.flatten(world).upload().render(cam, cfg)
     top = screen.rgb8[::-1]
     assert not top[:1].any() and top[1].any()
-    check_dragon(top, screen.accum[::-1] / 400.0, rel_tol=0.03)
+    check_dragon(top, _as_the_png_sees_it(screen.accum[::-1] / 400.0), rel_tol=0.03)
 
 
 @pytest.mark.gpu
@@ -160,7 +167,7 @@ def test_gpu_book2_against_reference_image(rtsr):
     top = screen.rgb8[::-1]
     assert not top[:10].any() and top[10].any()
     check_book2_light(top.min(axis=2) >= 250)
-    check_book2_regions(screen.accum[::-1] / 1000.0, rel_tol=0.05)
+    check_book2_regions(_as_the_png_sees_it(screen.accum[::-1] / 1000.0), rel_tol=0.05)
 
 
 @pytest.mark.gpu
