@@ -8,7 +8,7 @@
 //
 //   stream state  = Philox4x32-10( counter = {pixel_lo, pixel_hi, sample, 0},
 //                                  key     = {seed_lo, seed_hi} )     (128 bits)
-//   k-th draw     = k-th output of xoroshiro128++ started from that state
+//   k-th draw     = k-th output of xoroshiro128+ started from that state (only its high 53 / 52 bits are ever used)
 //   gen::<f64>()      = (u64 >> 11) * 2^-53  in [0,1)   (53 high bits: rand 0.8's Standard
 //                                                        distribution for f64)
 //   gen_range(a..b)   = v12 * (b - a) + (a - (b - a)),  v12 = bits(0x3FF0.. | u64 >> 12) in [1,2)
@@ -16,9 +16,13 @@
 //                        redraw when rounding lands exactly on b)
 //
 // Philox (Salmon et al., SC'11) gives statistically independent streams for
-// every (pixel, sample) at one evaluation per path; xoroshiro128++ (Blackman &
-// Vigna) is multiply-free, which matters on CDNA where 32-bit integer multiplies
-// are quarter rate and a path draws ~20-30 doubles.  Scheduling (which lane,
+// every (pixel, sample) at one evaluation per path; xoroshiro128+ (Blackman &
+// Vigna; the variant its authors recommend for floating-point generation from the upper
+// bits -- its weak LOW bits are shifted out here) is multiply-free, which matters on CDNA
+// where 32-bit integer multiplies are quarter rate and a path draws ~20-30 doubles, and it
+// is one 64-bit add and one rotation cheaper per draw than xoroshiro128++ (rounds 1 and 2 up
+// to here: 46 instead of 58 issue clocks per draw in the rejection loop that every
+// Lambertian / Metal / Isotropic scatter runs).  Scheduling (which lane,
 // wave, GPU or CPU thread runs a sample) cannot change any draw.
 #pragma once
 #include "rt_config.hpp"
@@ -77,13 +81,13 @@ RT_HD Rng rng_for_sample(uint64_t seed, uint64_t pixel_index, uint32_t sample) {
   return r;
 }
 
-// xoroshiro128++ (a=49, b=21, c=28; output rotl(s0+s1,17)+s0).
+// xoroshiro128+ 1.0 (a=24, b=16, c=37; output s0 + s1).
 RT_HD uint64_t rng_next_u64(Rng& r) {
   uint64_t s0 = r.s0, s1 = r.s1;
-  uint64_t result = rotl64(s0 + s1, 17) + s0;
+  uint64_t result = s0 + s1;
   s1 ^= s0;
-  r.s0 = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
-  r.s1 = rotl64(s1, 28);
+  r.s0 = rotl64(s0, 24) ^ s1 ^ (s1 << 16);
+  r.s1 = rotl64(s1, 37);
   return result;
 }
 
@@ -115,6 +119,20 @@ RT_HD double rng_range(Rng& r, double lo, double hi) {
   double offset = lo - scale;
   return u64_to_f64_1_2(rng_next_u64(r)) * scale + offset;
 }
+#endif
+
+// rng.gen_range(-1.0..1.0), the draw of the rejection samplers (vec3.rs:288-294, 310-322): value1_2 * 2 + (-3) in rand 0.8.5's
+// construction.  value1_2 * 2 is the same mantissa one exponent up, and 2 v - 3 is a multiple of 2^-51 below 1 in magnitude:
+// every step is exact, so building the number in [2, 4) directly and adding -3 returns the same bits with one f64
+// instruction less per draw (three per attempt of the rejection loop, the hottest loop of every workload).
+#if defined(RT_F32)
+RT_HD real rng_range_pm1(Rng& r) {
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)(rng_next_u64(r) >> 41) | 0x40000000u;  // [2, 4)
+  return c.f + -3.0f;
+}
+#else
+RT_HD double rng_range_pm1(Rng& r) { return bits_f64((rng_next_u64(r) >> 12) | 0x4000000000000000ull) + -3.0; }
 #endif
 
 // SplitMix64: host-side generator for scene construction (random sphere

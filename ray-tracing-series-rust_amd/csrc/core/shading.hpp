@@ -20,7 +20,8 @@ RT_HD Vec3 random_range_vec3(Rng& g, real mn, real mx) {
 }
 // One iteration of random_in_unit_sphere's rejection loop (vec3.rs:288-294): three draws, accept test.
 RT_HD bool sphere_sample_try(Rng& g, Vec3* p) {
-  *p = random_range_vec3(g, -real(1.0), real(1.0));
+  real x = rng_range_pm1(g), y = rng_range_pm1(g), z = rng_range_pm1(g);  // Vec3::random_range(-1.0, 1.0)
+  *p = v3(x, y, z);
   return length_squared(*p) < real(1.0);
 }
 // vec3.rs:287-295
@@ -35,7 +36,7 @@ RT_HD Vec3 random_unit_vector(Rng& g) { return unit(random_in_unit_sphere(g)); }
 // vec3.rs:310-322
 RT_HD Vec3 random_in_unit_disk(Rng& g) {
   for (;;) {
-    real x = rng_range(g, -real(1.0), real(1.0)), y = rng_range(g, -real(1.0), real(1.0));
+    real x = rng_range_pm1(g), y = rng_range_pm1(g);
     Vec3 p = v3(x, y, real(0.0));
     if (length_squared(p) < real(1.0)) return p;
   }

@@ -106,3 +106,56 @@ def test_sign_of_sine_is_exact(orc):
     want = np.where(np.isnan(s), 2.0, np.sign(s))
     got = orc.rt_math("sin_sign", x)
     assert np.array_equal(got, want), "%d mismatches" % int((got != want).sum())
+
+
+def test_gen_range_pm1_shortcut_is_exact():
+    """core/rng.hpp: rng_range_pm1 builds gen_range(-1.0..1.0) as bits(0x400.. | u >> 12) + -3 instead of rand 0.8.5's
+    value1_2 * scale + offset = bits(0x3FF.. | u >> 12) * 2 + -3 (UniformFloat::sample_single; vec3.rs:288-294 draws it three
+    times per attempt).  Every step of either form is exact, so the bits agree -- here on 4M random mantissas and the edges."""
+    import numpy as np
+    rs = np.random.RandomState(7)
+    m = rs.randint(0, 1 << 52, size=1 << 22, dtype=np.int64).astype(np.uint64)
+    m = np.concatenate([m, np.array([0, 1, (1 << 52) - 1, 1 << 51, (1 << 51) - 1, (1 << 51) + 1], dtype=np.uint64)])
+    a = (m | np.uint64(0x3FF0000000000000)).view(np.float64) * 2.0 + -3.0
+    b = (m | np.uint64(0x4000000000000000)).view(np.float64) + -3.0
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert a.min() == -1.0 and a.max() < 1.0
+    m32 = np.arange(1 << 23, dtype=np.uint32)  # every float mantissa (the f32 fast mode)
+    a32 = (m32 | np.uint32(0x3F800000)).view(np.float32) * np.float32(2.0) + np.float32(-3.0)
+    b32 = (m32 | np.uint32(0x40000000)).view(np.float32) + np.float32(-3.0)
+    assert np.array_equal(a32.view(np.uint32), b32.view(np.uint32))
+
+
+def test_stream_against_an_independent_python_restatement(orc):
+    """The whole stream definition of core/rng.hpp written out again in plain Python integers: Philox4x32-10 keyed by the render
+    seed over (pixel_lo, pixel_hi, sample, 0) -> the 128-bit state of xoroshiro128+ (a = 24, b = 16, c = 37) -> gen::<f64>() =
+    (u64 >> 11) * 2^-53.  Hand-checked anchor of the generator itself: from the state (1, 2) the outputs are 3 and 0x6001030003."""
+    M64 = (1 << 64) - 1
+
+    def rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & M64
+
+    def xoroshiro128plus(s0, s1):
+        while True:
+            yield (s0 + s1) & M64
+            s1 ^= s0
+            s0, s1 = rotl(s0, 24) ^ s1 ^ ((s1 << 16) & M64), rotl(s1, 37)
+
+    g = xoroshiro128plus(1, 2)
+    assert next(g) == 3 and next(g) == 0x6001030003
+
+    def philox(c, k0, k1):
+        c = list(c)
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k0, p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k1, p0 & 0xFFFFFFFF]
+            k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+        return c
+
+    for seed, pixel, sample in ((1, 10, 3), (0xDEADBEEF12345678, (1 << 33) + 5, 4_000_000_000), (0, 0, 0)):
+        c = philox((pixel & 0xFFFFFFFF, pixel >> 32, sample, 0), seed & 0xFFFFFFFF, seed >> 32)
+        s0, s1 = c[0] | (c[1] << 32), c[2] | (c[3] << 32)
+        assert s0 | s1
+        gen = xoroshiro128plus(s0, s1)
+        want = np.array([(next(gen) >> 11) * 2.0 ** -53 for _ in range(64)])
+        assert np.array_equal(_stream(orc, seed, pixel, sample, 64), want)
