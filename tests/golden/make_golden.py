@@ -7,9 +7,11 @@ for a few small renders, produced by oracle O1 -- the literal CPU restatement of
 CASES, outputs = arrays), not reference source.
 
 What they are not: outputs of the reference binary.  The reference is Rust seeded from the OS RNG and
-cannot be built or run in this environment, so no reference-produced image exists to compare with
-("parity unpinned" against reference output).  The goldens pin THIS build's CPU
-restatement so that later rounds' kernels (and the oracle itself) cannot drift silently.
+cannot be built or run in this environment, so nothing it produced can be matched bit for bit (bit-level
+parity is unpinned; what its three shipped images DO pin -- silhouettes, edges, region radiance -- is in
+reference_image_pins.json, see make_reference_image_pins.py and DESIGN.md section 2).  The goldens pin THIS
+build's CPU restatement so that later rounds' kernels (and the oracle itself) cannot drift silently; they
+are regenerated whenever the specified random stream changes (round 2: xoroshiro128++ -> xoroshiro128+).
 
     python tests/golden/make_golden.py        # rewrites *.npy / *.ppm / manifest.json
 """
