@@ -92,7 +92,8 @@ def build_roofline_tools(force=False, verbose=True):
     mix = os.path.join(LIB_DIR, "kernel_mix.json")
     calib = os.path.join(LIB_DIR, "issue_calib")
     tools = os.path.join(REPO_DIR, "tools")
-    deps = [os.path.join(PKG_DIR, "csrc"), tools]
+    # (tools/_gen holds this function's own intermediate files: not a dependency)
+    deps = [os.path.join(PKG_DIR, "csrc")] + [os.path.join(tools, f) for f in sorted(os.listdir(tools)) if os.path.isfile(os.path.join(tools, f))]
     if not force and not needs_build(mix, deps) and not needs_build(calib, deps):
         return mix
     gen_dir = os.path.join(tools, "_gen")
