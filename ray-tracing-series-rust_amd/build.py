@@ -29,6 +29,11 @@ HIP_SOURCES = [
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
     "-Wall", "-Wno-unused-function",
+    # MachineLICM hoists every f64 literal (two v_mov_b32) and every loop-invariant conversion out of the persistent loops; a
+    # 64-bit register pair built from two immediates is not rematerialisable, so the allocator then SPILLS those constants to
+    # scratch and reloads them inside the loops (k_trace_world: 141 dwords spilled / 264 B of scratch with the pass, 23 / 96
+    # without; k_trace_lds: 125 -> 116 VGPRs).  Materialising a constant where it is used costs two 2-clock moves.
+    "-mllvm", "-disable-machine-licm",
 ]
 
 
