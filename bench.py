@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--shard-of", type=int, default=0, help="analysis only (N = 1): render just rank 0's shard of an N-GPU job per step; "
                     "`value` is then N x this GPU's rate = what N GPUs would deliver before the gather")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2], help="frames pipelined (2: the tail, reduction, tone map and "
+                    "gather of frame k overlap the start of frame k + 1; 1: one frame at a time, e.g. under rocprofv3 --kernel-trace, whose "
+                    "start stamp of a queued kernel is taken before its waves can run)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="SAH bin count override (0 = library default)")
@@ -351,7 +354,7 @@ def main():
     # render workspace), two streams and two output buffers, so the tail of frame k -- its few 50-bounce paths in otherwise idle
     # waves, the ordered reduction, the tone map and (N > 1) the gather -- overlaps the start of frame k + 1.  Nothing is skipped:
     # every step still traces, reduces, tone-maps and gathers one full frame; the timed region ends when all of them have finished.
-    N_PIPE = 2
+    N_PIPE = args.frames_in_flight
     scenes = [flat.upload() for _ in range(N_PIPE)]
     scene = scenes[0]
     streams = [torch.cuda.Stream() for _ in range(N_PIPE)]

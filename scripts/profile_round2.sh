@@ -14,6 +14,9 @@ python3 bench.py --steps 20 --warmup 5 --keep-pmc $O/bench_c2_pmc > $O/bench_c2.
 echo "[profile] c2 done"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-pmc --no-extras --no-cpu-baseline > $O/bench_c2_stats_run.json 2> $O/stats.err ) || exit 1
 cp $(ls $O/stats/*/*_kernel_stats.csv | head -1) $O/bench_c2_kernel_stats.csv && rm -rf $O/stats
+# the same with one frame in flight: a queued kernel's start stamp is taken when its packet is accepted, before its waves can run
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 20 --warmup 5 --no-pmc --no-extras --no-cpu-baseline --frames-in-flight 1 > $O/bench_c2_stats_run_unpipelined.json 2> $O/stats1.err ) || exit 1
+cp $(ls $O/stats1/*/*_kernel_stats.csv | head -1) $O/bench_c2_kernel_stats_unpipelined.csv && rm -rf $O/stats1
 echo "[profile] stats done"
 python3 bench.py --workload head --steps 5 --warmup 1 --no-cpu-baseline --no-extras --keep-pmc $O/bench_head_pmc > $O/bench_head.json 2>> $O/bench.err || exit 1
 python3 bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --keep-pmc $O/bench_c4_pmc > $O/bench_c4.json 2>> $O/bench.err || exit 1
