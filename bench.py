@@ -280,8 +280,8 @@ def valu_roofline(pmc, pmc_info, calib, n_cu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (marks the run as non-headline)")
     ap.add_argument("--count-spp", type=int, default=32, help="spp of the instrumented counting run (same pixels and seeds)")
