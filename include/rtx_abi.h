@@ -255,6 +255,9 @@ typedef struct RtxMultiStats {
   double total_ms;        /* host wall time of the call: launches + gather + reorder + copy to the host */
   uint64_t gathered_bytes;
   int32_t n_shards, n_devices, used_rccl, reserved;
+  double gather_ms;       /* on the first device's stream: end of its own shard -> every shard gathered and put in row order
+                             (includes waiting for the slowest peer) */
+  double render_ms[16];   /* per device (first 16), as render_ms_max */
 } RtxMultiStats;
 rtx_status rtx_multi_create(const rtx_flat* f, int32_t n_shards, const int32_t* device_ids, int32_t block_rows,
                             rtx_multi** out);

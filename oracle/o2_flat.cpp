@@ -15,6 +15,7 @@
 // (see o1_literal.cpp header).
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <thread>
 #include <vector>
 #include "../ray-tracing-series-rust_amd/csrc/core/integrator.hpp"
@@ -66,22 +67,31 @@ int oracle_o2_render(const void* flat, const OracleCamera* cam, const OracleConf
   int threads = cfg->threads > 0 ? cfg->threads : 1;
   std::vector<rt::TraceCounters> tc((size_t)threads);
   for (auto& c : tc) memset(&c, 0, sizeof(c));
+  // Work is dealt in 8-pixel pieces of the shard's pixel list (row-major) from one atomic counter: a pixel's value does not depend
+  // on who computes it, and a shard of a few rows at a high sample count (the full-spp spot rows of tests/test_gpu_full_size.py)
+  // keeps every thread busy.
+  const size_t n_pix = rows.size() * (size_t)w, piece = 8;
+  std::atomic<size_t> next{0};
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t) {
     pool.emplace_back([&, t]() {
       rt::LocalStack<128> stack;
       stack.n = 0;
-      for (size_t lr = (size_t)t; lr < rows.size(); lr += (size_t)threads) {
-        int32_t j = rows[lr];
-        if (j >= row_limit) continue;
-        for (int32_t i = 0; i < w; ++i) {
+      for (;;) {
+        const size_t p0 = next.fetch_add(piece);
+        if (p0 >= n_pix) break;
+        const size_t p1 = p0 + piece < n_pix ? p0 + piece : n_pix;
+        for (size_t p = p0; p < p1; ++p) {
+          const size_t lr = p / (size_t)w;
+          const int32_t i = (int32_t)(p - lr * (size_t)w), j = rows[lr];
+          if (j >= row_limit) continue;
           rt::Color pixel = rt::v3(0, 0, 0);
           for (int32_t s = 0; s < rp.samples_per_pixel; ++s) {
             rt::Color c = counters ? rt::trace_sample<rt::F_ALL, true>(sv, rp, (uint32_t)i, (uint32_t)j, (uint32_t)s, stack, &tc[t])
                                    : rt::trace_sample<rt::F_ALL, false>(sv, rp, (uint32_t)i, (uint32_t)j, (uint32_t)s, stack, nullptr);
             pixel += c;
           }
-          size_t o = 3 * (lr * (size_t)w + (size_t)i);
+          size_t o = 3 * p;
           if (accum_rgb) { accum_rgb[o] = pixel.x; accum_rgb[o + 1] = pixel.y; accum_rgb[o + 2] = pixel.z; }
           if (rgb8) {
             int32_t c[3];

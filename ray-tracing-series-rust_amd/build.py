@@ -29,12 +29,36 @@ HIP_SOURCES = [
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
     "-Wall", "-Wno-unused-function",
-    # MachineLICM hoists every f64 literal (two v_mov_b32) and every loop-invariant conversion out of the persistent loops; a
-    # 64-bit register pair built from two immediates is not rematerialisable, so the allocator then SPILLS those constants to
-    # scratch and reloads them inside the loops (k_trace_world: 141 dwords spilled / 264 B of scratch with the pass, 23 / 96
-    # without; k_trace_lds: 125 -> 116 VGPRs).  Materialising a constant where it is used costs two 2-clock moves.
-    "-mllvm", "-disable-machine-licm",
 ]
+# Device side of the two compilations of render.hip ONLY (the persistent trace kernels it was measured on; not the host pass, not
+# lbvh.hip's radix sort, not the host sources).  MachineLICM hoists every f64 literal (two v_mov_b32) and every loop-invariant
+# conversion out of the persistent loops; a 64-bit register pair built from two immediates is not rematerialisable, so the
+# allocator then SPILLS those constants to scratch and reloads them inside the loops (k_trace_world: 141 dwords spilled / 264 B of
+# scratch with the pass, 23 / 96 without; k_trace_lds: 125 -> 116 VGPRs).  Materialising a constant where it is used costs two
+# 2-clock moves.  It is an internal LLVM option: probed once (an empty kernel), dropped if this toolchain does not know it, and
+# the outcome is recorded in lib/build_flags.json (bench.py prints it).
+LICM_FLAGS = ["-Xarch_device", "-mllvm=-disable-machine-licm"]
+TRACE_SOURCES = ("csrc/hip/render.hip", "csrc/hip/render_f32.hip")
+_licm_probe = None
+
+
+def licm_flags():
+    """LICM_FLAGS if hipcc accepts them (compiles an empty kernel once per process), else []."""
+    global _licm_probe
+    if _licm_probe is None:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[threadIdx.x] = 1.f; }\n")
+            rc = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-c", src, "-o", os.path.join(td, "probe.o")] + LICM_FLAGS,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        _licm_probe = list(LICM_FLAGS) if rc == 0 else []
+    return _licm_probe
+
+
+def flags_for(src):
+    return HIP_FLAGS + (licm_flags() if src in TRACE_SOURCES else [])
 
 
 def _hipcc():
@@ -70,7 +94,7 @@ def build_library(force=False, verbose=True):
     for src in HIP_SOURCES:
         obj = os.path.join(obj_dir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         if force or needs_build(obj, deps):
-            cmd = [_hipcc()] + HIP_FLAGS + ["-c", os.path.join(PKG_DIR, src), "-o", obj]
+            cmd = [_hipcc()] + flags_for(src) + ["-c", os.path.join(PKG_DIR, src), "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd, cwd=PKG_DIR)))
@@ -87,6 +111,10 @@ def build_library(force=False, verbose=True):
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=PKG_DIR)
+    import json
+    with open(os.path.join(LIB_DIR, "build_flags.json"), "w") as f:
+        json.dump({"hip_flags": HIP_FLAGS, "trace_kernel_flags": licm_flags(), "machine_licm_disabled": bool(licm_flags()),
+                   "trace_sources": list(TRACE_SOURCES)}, f, indent=1)
     return LIB_PATH
 
 
@@ -104,7 +132,7 @@ def build_roofline_tools(force=False, verbose=True):
     gen_dir = os.path.join(tools, "_gen")
     os.makedirs(gen_dir, exist_ok=True)
     asm = os.path.join(gen_dir, "render_gfx950.s")
-    flags = [f for f in HIP_FLAGS if f != "-fPIC"]
+    flags = [f for f in flags_for("csrc/hip/render.hip") if f != "-fPIC"]
     cmds = [
         [_hipcc()] + flags + ["-S", "--cuda-device-only", os.path.join(PKG_DIR, "csrc/hip/render.hip"), "-o", asm],
         [sys.executable, os.path.join(tools, "kernel_mix.py"), asm, mix],

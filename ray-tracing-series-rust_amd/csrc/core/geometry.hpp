@@ -67,9 +67,13 @@ RT_HD Point3 gravity_sphere_center(const FlatGravitySphere& s, const real* table
   else if (q >= real(18446744073709551615.0)) idx = ~0ull;
   else idx = (uint64_t)q;
   if (idx < ~0ull && idx + 1 <= (uint64_t)s.table_len) return v3(s.sx, table[s.table_first + (int64_t)idx], s.sz);
-  real t = s.time0, y = s.sy, vel = real(0.0);
-  while (t < time) {
-    t += incr;
+  // The clock of the loop is kept in double in BOTH compilations: `t += 0.001f` stops advancing at t >= 32768 (the increment is
+  // below half an ulp there) and the loop would never end; in the f64 build this is the reference's arithmetic unchanged.
+  // Renders reject shutter times more than 10 s past the stored table (render.hip: gravity_time_limit), which bounds the trip count.
+  double t = (double)s.time0;
+  real y = s.sy, vel = real(0.0);
+  while (t < (double)time) {
+    t += 0.001;
     vel -= real(0.000001);
     if (y - real(2.0) * s.radius <= real(0.0)) vel *= -real(0.8);
     y = rt_fmax(real(2.0) * s.radius, y + vel);

@@ -112,6 +112,7 @@ struct DeviceScene {
   int world_blocks_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};  // [book2 preset / any / all incl. gravity spheres / no sphere media][binary / wide]
   const struct WorldDesc* world_desc = nullptr;       // per-slot records of the world list for k_trace_world
   VoteTop vote_top;                   // the plain entries beside the BVH, for k_trace_vote's kernarg (n = -1: not applicable)
+  double gravity_time_limit = 1e300;  // scenes with GravitySpheres: the largest shutter time a render accepts (set at upload)
   uint32_t vote_tables = 0;           // wide k_trace_vote: materials | textures << 16 to keep in LDS (0: none; RTX_MAT_LDS=0)
   size_t vote_tables_bytes = 0;
   uint32_t world_mat_lds = 0, world_tex_lds = 0;  // material / texture records k_trace_world copies into LDS (RTX_MAT_LDS=0: none)
@@ -368,6 +369,11 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   int cur = -1;
   HIP_TRY(hipGetDevice(&cur));
   if (cur != ds->device) { set_error("render: scene was uploaded to a different device than the current one"); return RTX_EINVAL; }
+  if ((ds->view.features & rt::F_GRAVITY_SPHERE) && !(cam->time2 <= ds->gravity_time_limit)) {
+    set_error("render: shutter time " + std::to_string(cam->time2) + " is beyond the GravitySpheres' stored trajectory (limit " +
+              std::to_string(ds->gravity_time_limit) + " s): get_center's fallback loop (hit.rs:380-390) would run unbounded on the GPU");
+    return RTX_EINVAL;
+  }
 
   const rt::RenderParams rp = make_params(cam, cfg);
   const int32_t w = rp.image_width, h = rp.image_height;
@@ -382,7 +388,22 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   if (npix_all == 0) return RTX_OK;
 
   // ---- workspace
-  uint64_t budget = cfg->sample_buffer_bytes ? cfg->sample_buffer_bytes : (24ull << 30);  // of 288 GB: C5 takes 16 passes instead of 67, C3 8 instead of 40
+  // Default budget: 24 GiB (of 288 GB: C5 takes 16 passes instead of 67, C3 10 instead of 40), but never more than a third of the
+  // HBM that is free right now plus what this handle already holds -- other scene handles, a second frame in flight, torch's caching
+  // allocator or a smaller part shrink it, and a frame then takes more passes instead of failing.  An explicit
+  // cfg->sample_buffer_bytes is taken as given.
+  uint64_t budget = cfg->sample_buffer_bytes;
+  if (budget == 0) {
+    budget = 24ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const uint64_t avail = ((uint64_t)free_b + ds->samples_bytes) / 3;
+      if (avail < budget) budget = avail;
+    } else {
+      (void)hipGetLastError();
+    }
+    if (budget < ds->samples_bytes) budget = ds->samples_bytes;  // what is already there can be used
+  }
   uint64_t per_sample_plane = npix * 24ull;
   uint32_t spp = (uint32_t)cfg->samples_per_pixel;
   uint32_t spp_pass = spp;
@@ -396,7 +417,19 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   size_t need_samples = (size_t)spp_pass * per_sample_plane;
   if (need_samples > ds->samples_bytes) {
     if (ds->samples) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(ds->samples)); ds->samples = nullptr; ds->samples_bytes = 0; }
-    HIP_TRY(hipMalloc((void**)&ds->samples, need_samples));
+    // out of memory: halve the pass until the buffer fits (down to one sample per pass) before giving up
+    for (;;) {
+      hipError_t me = hipMalloc((void**)&ds->samples, need_samples);
+      if (me == hipSuccess) break;
+      (void)hipGetLastError();
+      ds->samples = nullptr;
+      if (me != hipErrorOutOfMemory || spp_pass <= 1) {
+        set_error(std::string("render: sample buffer of ") + std::to_string(need_samples) + " bytes: " + hipGetErrorString(me));
+        return me == hipErrorOutOfMemory ? RTX_ENOMEM : RTX_EHIP;
+      }
+      spp_pass = (spp_pass + 1) / 2;
+      need_samples = (size_t)spp_pass * per_sample_plane;
+    }
     ds->samples_bytes = need_samples;
   }
   double* accum = d_accum_out;
@@ -724,6 +757,12 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
   v.max_stack = fs.max_stack;
   v.features = fs.features;
   ds->n_nodes = (int32_t)fs.nodes.size();
+  // GravitySphere::get_center (hit.rs:369-391) leaves its stored trajectory for a brute-force loop of (time - time0) / 0.001
+  // steps, per sphere test, per ray: a shutter far beyond the table is an effectively unbounded kernel.  Renders are limited to
+  // RTX_GRAVITY_SLACK_S seconds past the shortest table (10 000 loop steps); rtx_render* return RTX_EINVAL beyond.
+  ds->gravity_time_limit = 1e300;
+  for (const rt::FlatGravitySphere& g : fs.gravity_spheres)
+    ds->gravity_time_limit = std::min(ds->gravity_time_limit, (double)g.table_len * 0.001 + 10.0);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0)
