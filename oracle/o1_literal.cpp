@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -963,6 +964,55 @@ int oracle_o1_render(const void* graph_ptr, int32_t world_handle, const OracleCa
             rgb8[o] = (uint8_t)c[0]; rgb8[o + 1] = (uint8_t)c[1]; rgb8[o + 2] = (uint8_t)c[2];
           }
         }
+      }
+    });
+  }
+  for (std::thread& th : pool) th.join();
+  return 0;
+}
+
+// The same per-pixel loop over a rectangle of the frame only: rows [j0, j1) counted from the BOTTOM row, columns [i0, i1).
+// A pixel is a pure function of (scene, camera, config, i, j), so the window equals that part of the whole frame; it lets a test
+// spend its samples on the regions the reference's images pin (tests/test_reference_image_pins.py) instead of on 10^6 pixels.
+// accum_rgb: (j1 - j0) x (i1 - i0) x 3, the window's bottom row first.  Pixels are dealt to the threads one by one.
+int oracle_o1_render_window(const void* graph_ptr, int32_t world_handle, const OracleCamera* cam, const OracleConfig* cfg,
+                            int32_t j0, int32_t j1, int32_t i0, int32_t i1, double* accum_rgb) {
+  if (!graph_ptr || !cam || !cfg || !accum_rgb) return 1;
+  const rtx::SceneGraph* g = (const rtx::SceneGraph*)graph_ptr;
+  if (!g->valid_hittable(world_handle)) return 1;
+  const int32_t w = cfg->image_width, h = cfg->image_height;
+  if (j0 < 0 || j1 > h || i0 < 0 || i1 > w || j0 >= j1 || i0 >= i1) return 1;
+  World wb;
+  wb.g = g;
+  wb.textures.resize(g->textures.size());
+  wb.materials.resize(g->materials.size());
+  wb.bvh_rng.state = cfg->bvh_seed;
+  HittablePtr world = wb.hittable(world_handle);
+  Camera camera = to_camera(cam);
+  const int32_t spp = cfg->samples_per_pixel, max_depth = cfg->max_depth;
+  const Color background(cfg->background[0], cfg->background[1], cfg->background[2]);
+  const int threads = cfg->threads > 0 ? cfg->threads : 1;
+  const int64_t ww = i1 - i0, n_pix = (int64_t)(j1 - j0) * ww;
+  std::atomic<int64_t> next{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&]() {
+      for (;;) {
+        const int64_t p = next.fetch_add(1);
+        if (p >= n_pix) break;
+        const int32_t j = j0 + (int32_t)(p / ww), i = i0 + (int32_t)(p % ww);
+        Vec3 pixel(0, 0, 0);
+        const uint64_t pixel_index = (uint64_t)j * (uint64_t)w + (uint64_t)i;
+        for (int32_t s = 0; s < spp; ++s) {
+          Rng rng = rt::rng_for_sample(cfg->seed, pixel_index, (uint32_t)s);
+          double ru = rt::rng_f64(rng);
+          double u = ((double)i + ru) / (double)(w - 1);  // world.rs:1212
+          double rv = rt::rng_f64(rng);
+          double v = ((double)j + rv) / (double)(h - 1);  // world.rs:1213
+          Ray r = camera.get_ray(u, v, rng);
+          pixel += ray_color(r, background, *world, max_depth, rng);
+        }
+        accum_rgb[3 * p] = pixel.x(); accum_rgb[3 * p + 1] = pixel.y(); accum_rgb[3 * p + 2] = pixel.z();
       }
     });
   }

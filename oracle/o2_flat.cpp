@@ -14,6 +14,7 @@
 // Parity status vs the reference's OUTPUT: statistical pins against its three images, bit-level parity unpinned
 // (see o1_literal.cpp header).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <atomic>
 #include <thread>
@@ -203,6 +204,88 @@ int oracle_audit_flat(const void* flat, int32_t* max_depth_out) {
   return max_depth <= fs.max_stack + 1 ? 0 : 6;
 }
 
+// Audit of the time-aware culling boxes (FlatMotion32): for every BVH that carries them and `n_times` instants of its interval
+// (both ends included), every child box -- evaluated in f32 exactly as k_trace_lds does: s32 = fl((t - t0) * inv_dt) clamped to
+// [0, 1], plane = fmaf(s32, slope, plane0) -- must contain the f64 box of every sphere below that child at that instant.
+// Returns 0 when it does, else a positive code; *checked = (box, primitive, instant) triples looked at.
+static void motion_collect(const rtx::FlatScene& fs, const rt::FlatEntry& e, int32_t child, std::vector<rt::PrimRef>* out) {
+  if (rt::node_child_is_leaf(child)) {
+    for (uint32_t i = 0; i < rt::leaf_count(child); ++i) out->push_back(fs.refs[(size_t)e.b + rt::leaf_first(child) + i]);
+    return;
+  }
+  motion_collect(fs, e, fs.nodes[(size_t)child].child[0], out);
+  motion_collect(fs, e, fs.nodes[(size_t)child].child[1], out);
+}
+int oracle_audit_motion(const void* flat, int32_t n_times, int64_t* checked) {
+  if (!flat || n_times < 2) return -1;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  int64_t n_checked = 0;
+  if (checked) *checked = 0;
+  if (fs.motion32.empty()) return 0;
+  if (fs.motion32.size() != fs.nodes.size()) return 1;
+  for (const rt::FlatEntry& e : fs.entries) {
+    if (e.kind != rt::ENTRY_BVH || e.a < 0 || !(e.f[0] < e.f[1])) continue;
+    std::vector<int32_t> todo{e.a};
+    while (!todo.empty()) {
+      const int32_t n = todo.back();
+      todo.pop_back();
+      const rt::FlatMotion32& m = fs.motion32[(size_t)n];
+      for (int c = 0; c < 2; ++c) {
+        const int32_t child = fs.nodes[(size_t)n].child[c];
+        if (!rt::node_child_is_leaf(child)) todo.push_back(child);
+        std::vector<rt::PrimRef> prims;
+        motion_collect(fs, e, child, &prims);
+        for (int32_t k = 0; k < n_times; ++k) {
+          // instants: the two ends, then a low-discrepancy sweep of the interior
+          const double u = k == 0 ? 0.0 : (k == 1 ? 1.0 : std::fmod(0.6180339887498949 * (double)k, 1.0));
+          const double t = e.f[0] + u * (e.f[1] - e.f[0]);
+          const double inv_dt = 1.0 / (e.f[1] - e.f[0]);
+          const float s32 = std::fmin(std::fmax((float)((t - e.f[0]) * inv_dt), 0.f), 1.f);
+          for (rt::PrimRef ref : prims) {
+            const uint32_t idx = rt::primref_index(ref), ty = rt::primref_type(ref);
+            double c3[3], r;
+            if (ty == rt::PRIM_SPHERE) { const rt::FlatSphere& sp = fs.spheres[idx]; c3[0] = sp.cx; c3[1] = sp.cy; c3[2] = sp.cz; r = sp.radius; }
+            else if (ty == rt::PRIM_MOVING_SPHERE) {
+              const rt::FlatMovingSphere& sp = fs.moving_spheres[idx];
+              const rt::Vec3 cc = rt::moving_sphere_center(sp, t);
+              c3[0] = cc.x; c3[1] = cc.y; c3[2] = cc.z; r = sp.radius;
+            } else return 2;  // motion boxes are only built for BVHs of spheres and moving spheres... and whatever else is static
+            for (int a = 0; a < 3; ++a) {
+              const float lo = std::fmaf(s32, m.dlo[c][a], m.lo0[c][a]), hi = std::fmaf(s32, m.dhi[c][a], m.hi0[c][a]);
+              if (!((double)lo <= c3[a] - std::fabs(r)) || !((double)hi >= c3[a] + std::fabs(r))) return 3;
+              ++n_checked;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (checked) *checked = n_checked;
+  return 0;
+}
+// Mean half-area of the leaf boxes of the time-aware tree at the middle of the interval over that of the static (union) boxes:
+// what the time-aware test can cull that the static one cannot (diagnostic for tests / DESIGN).
+double oracle_motion_leaf_area_ratio(const void* flat) {
+  if (!flat) return -1.0;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  if (fs.motion32.empty()) return 1.0;
+  double a_static = 0.0, a_motion = 0.0;
+  for (size_t n = 0; n < fs.nodes.size(); ++n)
+    for (int c = 0; c < 2; ++c) {
+      if (!rt::node_child_is_leaf(fs.nodes[n].child[c])) continue;
+      const rt::FlatNode32& q = fs.nodes32[n];
+      const rt::FlatMotion32& m = fs.motion32[n];
+      double d[3], e[3];
+      for (int a = 0; a < 3; ++a) {
+        d[a] = (double)q.hi[c][a] - (double)q.lo[c][a];
+        e[a] = ((double)m.hi0[c][a] + 0.5 * (double)m.dhi[c][a]) - ((double)m.lo0[c][a] + 0.5 * (double)m.dlo[c][a]);
+      }
+      a_static += d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+      a_motion += e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+  return a_static > 0.0 ? a_motion / a_static : 1.0;
+}
+
 void oracle_philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1) { rt::philox4x32_10(ctr, k0, k1); }
 uint64_t oracle_splitmix64_next(uint64_t* state) {
   rt::HostRng h{*state};
@@ -231,3 +314,93 @@ void oracle_rt_math(int32_t fn, const double* x, const double* y, int64_t n, dou
 }
 
 }  // extern "C"
+// The walk k_trace_lds does, on the CPU, for worlds that are ONE BVH of spheres: the f32 culling tree (static boxes, or the
+// time-aware boxes when use_motion != 0) visited near child first, every hit decided by the f64 primitive tests, one path at a
+// time.  Two uses: (1) its frame must equal oracle_o2_render's bit for bit -- the culling structure cannot be seen; (2) its
+// counters say what the time-aware boxes save: counts[0] = rays, [1] = node visits (two box tests each), [2] = primitive tests.
+extern "C" int oracle_lds_walk_render(const void* flat, const OracleCamera* cam, const OracleConfig* cfg, int32_t use_motion,
+                                      int32_t row_stride, double* accum_rgb, uint64_t counts[3]) {
+  if (!flat || !cam || !cfg || row_stride <= 0) return 1;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  if (fs.top_level.size() != 1 || fs.entries[fs.top_level[0]].kind != rt::ENTRY_BVH) return 2;
+  if (use_motion && fs.motion32.empty()) return 3;
+  const rt::FlatEntry& be = fs.entries[fs.top_level[0]];
+  const rt::SceneView sv = fs.view();
+  const rt::RenderParams rp = make_params(cam, cfg);
+  const int32_t w = rp.image_width, h = rp.image_height;
+  std::vector<int32_t> rows;
+  for (int32_t j = 0; j < h; j += row_stride) rows.push_back(j);
+  const int threads = cfg->threads > 0 ? cfg->threads : 1;
+  std::vector<uint64_t> tc((size_t)threads * 3, 0);
+  std::atomic<size_t> next{0};
+  const double m_t0 = be.f[0], m_inv = use_motion ? 1.0 / (be.f[1] - be.f[0]) : 0.0;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      std::vector<int32_t> stack(256);
+      for (;;) {
+        const size_t p = next.fetch_add(1);
+        if (p >= rows.size() * (size_t)w) break;
+        const int32_t j = rows[p / (size_t)w], i = (int32_t)(p % (size_t)w);
+        rt::Color pixel = rt::v3(0, 0, 0);
+        for (int32_t s = 0; s < rp.samples_per_pixel; ++s) {
+          rt::PathState ps;
+          rt::path_begin(rp, (uint32_t)i, (uint32_t)j, (uint32_t)s, &ps);
+          for (;;) {
+            if (rt::path_bounce_begin(&ps)) break;
+            tc[3 * t]++;
+            const rt::Ray32 q = rt::make_ray32(ps.ray, rt::ray_t_min(ps.ray));
+            const uint32_t dir_neg = rt::ray_dir_neg(ps.ray);
+            const float s32 = std::fmin(std::fmax((float)((ps.ray.time - m_t0) * m_inv), 0.f), 1.f);
+            float t_max32 = __builtin_huge_valf();
+            rt::Closest best; best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
+            int n_stack = 0;
+            int32_t cur = be.a;
+            for (;;) {
+              if (cur >= 0) {
+                tc[3 * t + 1]++;
+                const rt::FlatNode32& nd = fs.nodes32[(size_t)cur];
+                float lo[2][3], hi[2][3];
+                for (int c = 0; c < 2; ++c)
+                  for (int a = 0; a < 3; ++a) {
+                    if (use_motion) {
+                      const rt::FlatMotion32& m = fs.motion32[(size_t)cur];
+                      lo[c][a] = std::fmaf(s32, m.dlo[c][a], m.lo0[c][a]); hi[c][a] = std::fmaf(s32, m.dhi[c][a], m.hi0[c][a]);
+                    } else { lo[c][a] = nd.lo[c][a]; hi[c][a] = nd.hi[c][a]; }
+                  }
+                const int first = (int)((dir_neg >> (uint32_t)nd.axis) & 1u);
+                const bool hf = rt::cull32_may_hit(lo[first], hi[first], q, t_max32), hs = rt::cull32_may_hit(lo[1 - first], hi[1 - first], q, t_max32);
+                const int32_t cf = nd.child[first], cs = nd.child[1 - first];
+                // leaves are kept as their (negative) codes, -1 never occurs as a code (0x80000000 | ...), INT32_MIN + x < -1
+                if (hf) { cur = cf; if (hs) stack[(size_t)n_stack++] = cs; }
+                else if (hs) cur = cs;
+                else if (n_stack > 0) cur = stack[(size_t)--n_stack];
+                else break;
+              } else {
+                const uint32_t f = rt::leaf_first(cur), k = rt::leaf_count(cur);
+                for (uint32_t x = 0; x < k; ++x) {
+                  tc[3 * t + 2]++;
+                  rt::offer_prim<rt::F_ALL, false>(sv, fs.refs[(size_t)be.b + f + x], f + x, ps.ray, rt::ray_t_min(ps.ray), &best, nullptr);
+                }
+                t_max32 = rt::cull_round_up(best.t);
+                if (n_stack > 0) cur = stack[(size_t)--n_stack];
+                else break;
+              }
+            }
+            rt::HitRecord rec;
+            if (best.hit) rt::prim_finalize<rt::F_ALL>(sv, best.ref, ps.ray, best.t, &rec);
+            if (rt::path_bounce_end<rt::F_ALL, false>(sv, rp, &ps, best.hit, rec, nullptr)) break;
+          }
+          pixel += ps.output;
+        }
+        if (accum_rgb) { accum_rgb[3 * p] = pixel.x; accum_rgb[3 * p + 1] = pixel.y; accum_rgb[3 * p + 2] = pixel.z; }
+      }
+    });
+  }
+  for (std::thread& th : pool) th.join();
+  if (counts) {
+    counts[0] = counts[1] = counts[2] = 0;
+    for (int t = 0; t < threads; ++t) for (int k = 0; k < 3; ++k) counts[k] += tc[3 * (size_t)t + k];
+  }
+  return 0;
+}

@@ -31,6 +31,8 @@ typedef struct OracleCounters {
 /* O1: literal object-graph restatement (oracle/o1_literal.cpp).  graph = rtx_builder_graph(). */
 int oracle_o1_render(const void* graph, int32_t world_handle, const OracleCamera* cam,
                      const OracleConfig* cfg, double* accum_rgb, uint8_t* rgb8);
+int oracle_o1_render_window(const void* graph, int32_t world_handle, const OracleCamera* cam, const OracleConfig* cfg,
+                            int32_t j0, int32_t j1, int32_t i0, int32_t i1, double* accum_rgb);
 /* O2: CPU loop over the product's FLATTENED arrays through the product's shared core headers
  * (oracle/o2_flat.cpp).  flat = rtx_flat_arrays().  Renders the shard
  * { j : (j / block_rows) % shard_count == shard_index } compacted, like rtx_render_device.
@@ -66,6 +68,10 @@ int oracle_core_aabb_hit(const double mn[3], const double mx[3], const double o[
 int oracle_core_world_hit(const void* flat, const double o[3], const double d[3], double time, double t_min,
                           double t_max, uint64_t rng_seed, double out[10]);
 int oracle_audit_flat(const void* flat, int32_t* max_depth_out);
+int oracle_audit_motion(const void* flat, int32_t n_times, int64_t* checked);
+double oracle_motion_leaf_area_ratio(const void* flat);
+int oracle_lds_walk_render(const void* flat, const OracleCamera* cam, const OracleConfig* cfg, int32_t use_motion,
+                           int32_t row_stride, double* accum_rgb, uint64_t counts[3]);
 
 /* Shared-core probes (product headers compiled for the host): RNG and rt_math. */
 void oracle_philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1);

@@ -81,6 +81,10 @@ def load():
     lib.oracle_core_world_hit.argtypes = [C.c_void_p, _D, _D, C.c_double, C.c_double, C.c_double, C.c_uint64, _D]
     lib.oracle_audit_flat.restype = C.c_int
     lib.oracle_audit_flat.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.oracle_audit_motion.restype = C.c_int
+    lib.oracle_audit_motion.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    lib.oracle_motion_leaf_area_ratio.restype = C.c_double
+    lib.oracle_motion_leaf_area_ratio.argtypes = [C.c_void_p]
     lib.oracle_philox4x32_10.restype = None
     lib.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
     lib.oracle_splitmix64_next.restype = C.c_uint64
@@ -129,6 +133,23 @@ def o1_render(graph_ptr, world, rtx_cam, rtx_cfg, image_height, threads=None, bv
     if rc != 0:
         raise RuntimeError("oracle_o1_render failed (%d)" % rc)
     return accum, rgb8
+
+
+def o1_render_window(graph_ptr, world, rtx_cam, rtx_cfg, image_height, top_box, threads=None, bvh_seed=12345):
+    """The literal restatement over a rectangle of the frame.  top_box = (r0, r1, c0, c1) with rows counted from the TOP of the
+    image (as the reference-image pins are); returns accum[r1 - r0, c1 - c0, 3], top row first."""
+    lib = load()
+    cam = camera_from(rtx_cam)
+    cfg = config_from(rtx_cfg, image_height, threads, bvh_seed)
+    r0, r1, c0, c1 = top_box
+    j0, j1 = image_height - r1, image_height - r0
+    accum = np.zeros((j1 - j0, c1 - c0, 3), dtype=np.float64)
+    lib.oracle_o1_render_window.restype = C.c_int
+    rc = lib.oracle_o1_render_window(C.c_void_p(graph_ptr), C.c_int32(world), C.byref(cam), C.byref(cfg), C.c_int32(j0), C.c_int32(j1),
+                                     C.c_int32(c0), C.c_int32(c1), accum.ctypes.data_as(_D))
+    if rc != 0:
+        raise RuntimeError("oracle_o1_render_window failed (%d)" % rc)
+    return accum[::-1]
 
 
 def o2_render(flat_arrays_ptr, rtx_cam, rtx_cfg, image_height, shard=(0, 1, 1), threads=None, counters=False):
@@ -228,6 +249,33 @@ def o1_hit(graph_ptr, handle, o, d, time=0.0, t_min=0.001, t_max=float("inf"), r
 def core_world_hit(flat_arrays_ptr, o, d, time=0.0, t_min=0.001, t_max=float("inf"), rng_seed=1):
     out = (C.c_double * 10)()
     return _rec(load().oracle_core_world_hit(flat_arrays_ptr, _d3(o), _d3(d), time, t_min, t_max, rng_seed, out), out)
+
+
+def audit_motion(flat_arrays_ptr, n_times=16):
+    """(code, triples checked): the time-aware boxes contain every sphere below them at n_times instants (0 = consistent)."""
+    n = C.c_int64(0)
+    rc = load().oracle_audit_motion(flat_arrays_ptr, n_times, C.byref(n))
+    return rc, n.value
+
+
+def lds_walk_render(flat_arrays_ptr, rtx_cam, rtx_cfg, image_height, use_motion, row_stride=1, threads=None):
+    """The LDS kernel's walk on the CPU (f32 culling tree, static or time-aware boxes): (accum of rows 0, stride, .., counts)."""
+    lib = load()
+    cam = camera_from(rtx_cam)
+    cfg = config_from(rtx_cfg, image_height, threads)
+    rows = list(range(0, image_height, row_stride))
+    accum = np.zeros((len(rows), rtx_cfg.image_width, 3), dtype=np.float64)
+    counts = (C.c_uint64 * 3)()
+    lib.oracle_lds_walk_render.restype = C.c_int
+    rc = lib.oracle_lds_walk_render(C.c_void_p(flat_arrays_ptr), C.byref(cam), C.byref(cfg), C.c_int32(1 if use_motion else 0),
+                                    C.c_int32(row_stride), accum.ctypes.data_as(_D), counts)
+    if rc != 0:
+        raise RuntimeError("oracle_lds_walk_render failed (%d)" % rc)
+    return accum, {"rays": counts[0], "node_visits": counts[1], "prim_tests": counts[2]}
+
+
+def motion_leaf_area_ratio(flat_arrays_ptr):
+    return load().oracle_motion_leaf_area_ratio(flat_arrays_ptr)
 
 
 def audit_flat(flat_arrays_ptr):

@@ -81,6 +81,19 @@ struct FlatNode32 {  // 64 B
   int32_t axis;
   int32_t pad;
 };
+// Time-aware culling boxes, node i mirroring node i of `nodes` (present when a BVH of the scene holds MovingSpheres, whose
+// centre is LINEAR in time, hit.rs:275-278).  With s = (ray.time - time0) / (time1 - time0) of the BVH's own interval
+// (BvhNode::from_list(list, time0, time1), bvh.rs:85-93; FlatEntry::f[0], f[1]), child c's box at that instant is contained in
+//     [lo0 + s dlo, hi0 + s dhi]    for every s in [0, 1]
+// evaluated in f32 with one fma per plane: the end boxes are the unions of the subtree's primitive boxes AT time0 and AT time1
+// (the lerp of two unions contains the union of the lerps: min of linear functions is concave), pushed outward by 2^-21 of the
+// axis' largest coordinate, which covers the rounding of s, of the differences and of the fma.  The reference's own boxes are
+// the unions OVER the interval (hit.rs:317-327): a sphere that rises 5 units during the shutter (Book-1 at HEAD) has a box 27
+// times its size there, and every ray tests it whatever its own time.  A BVH is a culling structure: the image cannot change.
+struct FlatMotion32 {  // 96 B
+  float lo0[2][3], hi0[2][3];
+  float dlo[2][3], dhi[2][3];
+};
 RT_HD bool node_child_is_leaf(int32_t c) { return c < 0; }
 RT_HD uint32_t leaf_first(int32_t c) { return ((uint32_t)c & 0x7fffffffu) >> 3; }
 RT_HD uint32_t leaf_count(int32_t c) { return ((uint32_t)c & 7u) + 1u; }
@@ -92,12 +105,12 @@ RT_HD int32_t make_leaf(uint32_t first, uint32_t count) {
 enum EntryKind : int32_t {
   ENTRY_PRIM = 0,    // a = PrimRef
   ENTRY_GROUP = 1,   // ordered list semantics (HittableList / RectPrism): a = first ref, b = count
-  ENTRY_BVH = 2,     // a = root node, b = first ref of its prim-ref list, c = ref count
-  ENTRY_XFORM = 3,   // a = child entry (PRIM/GROUP/BVH), b = number of ops (outermost first)
+  ENTRY_BVH = 2,     // a = root node, b = first ref of its prim-ref list, c = ref count; f[0], f[1] = time0, time1 of from_list
+  ENTRY_XFORM = 3,   // a = child entry (PRIM/GROUP/BVH), b = number of ops (outermost first, <= RT_MAX_XFORM_OPS)
   ENTRY_MEDIUM = 4,  // a = boundary entry (PRIM/GROUP/BVH/XFORM), b = phase material; f[0] = -1/density
 };
 enum XformOp : int32_t { XFORM_TRANSLATE = 0, XFORM_ROTATE_Y = 1 };
-#define RT_MAX_XFORM_OPS 2
+#define RT_MAX_XFORM_OPS 4  // Translate / RotateY wrappers around one object (hit.rs:787-936); deeper chains: RTX_EUNSUPPORTED
 struct FlatXformOp {
   int32_t op;
   int32_t pad;
@@ -162,6 +175,7 @@ struct SceneView {
   const FlatTriangle* triangles;
   const FlatNode* nodes;
   const FlatNode32* nodes32;
+  const FlatMotion32* motion32;  // null unless a BVH holds MovingSpheres
   const PrimRef* refs;
   const FlatEntry* entries;
   const int32_t* top_level;  // entry indices, in HittableList order

@@ -502,6 +502,18 @@ RT_HD void xform_record(const FlatXformOp& op, const Ray& child_ray, HitRecord* 
   create_normal_face(child_ray, n, &rec->normal, &rec->front_face);
 }
 
+// The way back out of a chain of ops (outermost first): innermost op first, each against the ray IT handed to its child.  That
+// ray is recomputed from the outer ray for every op but the innermost (whose child ray is `innermost_ray`, already at hand)
+// instead of being kept live across the walk.
+RT_HD void xform_record_chain(const FlatXformOp* ops, int nops, const Ray& outer, const Ray& innermost_ray, HitRecord* rec) {
+  xform_record(ops[nops - 1], innermost_ray, rec);
+  for (int k = nops - 2; k >= 0; --k) {
+    Ray c = outer;
+    for (int j = 0; j <= k; ++j) c = xform_ray(ops[j], c);
+    xform_record(ops[k], c, rec);
+  }
+}
+
 // The world: HittableList::hit over the ordered top-level table (hit.rs:660-690), with
 // Translate / RotateY (hit.rs:802-823, 892-931) and ConstantMedium (hit.rs:955-986) handled
 // around ONE geometry query site so the traversal code exists once in the kernel.
@@ -535,7 +547,7 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, real t_min, real t_max, 
     FlatEntry solid_rec = e_rec;
     if (is_medium) solid_rec = rt_load_uniform(&sv.entries[e->a]);
     const FlatEntry* solid = &solid_rec;
-    // the ray as the innermost geometry sees it (up to two transform ops, outermost first); the
+    // the ray as the innermost geometry sees it (up to RT_MAX_XFORM_OPS transform ops, outermost first); the
     // intermediate ray is recomputed for the way back instead of being kept live across the walk
     const bool is_xform = (F & F_XFORM) && solid->kind == ENTRY_XFORM;
     Ray rq = r;
@@ -544,8 +556,7 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, real t_min, real t_max, 
     if (is_xform) {
       nops = solid->b;
       geom_rec = rt_load_uniform(&sv.entries[solid->a]);
-      rq = xform_ray(solid->ops[0], r);
-      if (nops > 1) rq = xform_ray(solid->ops[1], rq);
+      for (int k = 0; k < nops; ++k) rq = xform_ray(solid->ops[k], rq);
     }
 
     Closest best;
@@ -582,14 +593,7 @@ RT_HD bool world_hit(const SceneView& sv, const Ray& r, real t_min, real t_max, 
       rec->mat = e->b;
     } else {
       prim_finalize<F>(sv, best.ref, rq, best.t, rec);
-      if (is_xform) {
-        if (nops > 1) {
-          xform_record(solid->ops[1], rq, rec);
-          xform_record(solid->ops[0], xform_ray(solid->ops[0], r), rec);
-        } else {
-          xform_record(solid->ops[0], rq, rec);
-        }
-      }
+      if (is_xform) xform_record_chain(solid->ops, nops, r, rq, rec);
     }
     hit_anything = true;
     closest_so_far = rec->t;

@@ -1,6 +1,7 @@
 // Host-only entry points of include/rtx_abi.h: builder (one call per reference constructor),
 // camera/config, scene catalogue, flatten, PPM output.  Device entry points: render.hip.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -188,6 +189,8 @@ rtx_status rtx_flatten(const rtx_builder* b, rtx_handle world, const RtxBuildOpt
     opt.gpu_builder = options->gpu_builder ? 1 : 0;
     if (options->bvh_seed) opt.bvh_seed = options->bvh_seed;
   }
+  if (const char* e = getenv("RTX_LEAF_FIRST")) opt.leaf_first = atoi(e) != 0 ? 1 : 0;  // A/B switches, never change a result
+  if (const char* e = getenv("RTX_MOTION_TOPOLOGY")) opt.motion_topology = atoi(e) != 0 ? 1 : 0;
   rtx_flat* f = new (std::nothrow) rtx_flat();
   if (!f) { set_error("out of memory"); return RTX_ENOMEM; }
   std::string err;

@@ -13,7 +13,7 @@
 enum RtxF32Array : int {
   RTX32_SPHERES = 0, RTX32_MOVING_SPHERES, RTX32_RECTS, RTX32_TRIANGLES, RTX32_NODES, RTX32_NODES32, RTX32_REFS,
   RTX32_ENTRIES, RTX32_TOP_LEVEL, RTX32_MATERIALS, RTX32_TEXTURES, RTX32_PERLINS, RTX32_IMAGES, RTX32_TEXELS,
-  RTX32_TOP_BOX32, RTX32_GRAVITY_SPHERES, RTX32_GRAVITY_Y, RTX32_N_ARRAYS
+  RTX32_TOP_BOX32, RTX32_GRAVITY_SPHERES, RTX32_GRAVITY_Y, RTX32_MOTION32, RTX32_N_ARRAYS
 };
 struct RtxF32Blobs {
   const void* data[RTX32_N_ARRAYS];

@@ -45,6 +45,7 @@ struct WorldDesc;
 
 struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
   uint32_t n_nodes, n_refs, n_spheres, n_moving;
+  uint32_t node_dwords;  // LDSK_NODE_DWORDS, or LDSK_MOTION_NODE_DWORDS for the time-aware instantiation
 };
 
 // The plain primitive entries beside the BVH in the world list (the dragon room's seven rectangles), as a kernel argument:
@@ -96,11 +97,17 @@ struct DeviceScene {
   uint32_t walk_threshold = 18;       // RTX_WALK_THRESHOLD (1 = never carry a walk over); 18 measured best on C2 (12..22 within 1 %)
   uint32_t regen_min = 1;             // wide k_trace_vote: lanes that must be waiting before the wave regenerates (RTX_REGEN_MIN)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
+  // the same plan for the time-aware instantiation (bigger node records: its own ring size); chosen per render, when the camera's
+  // shutter lies inside the BVH's time interval [motion_t0, motion_t1] (RTX_MOTION=0 turns it off)
+  bool motion_ok = false, motion_ring = false;
+  uint32_t motion_ring_cap = 0;
+  LdsSceneDims motion_dims = {0, 0, 0, 0, 0};
+  double motion_t0 = 0.0, motion_t1 = 0.0;
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
   uint32_t lds_ring_cap = 64;         // entries per wave ring: 64, or 48 / 32 when the scene leaves less LDS
   uint32_t lds_chunk = TRACE_CHUNK_DEFAULT;  // sample indices a wave reserves per grab (RTX_CHUNK)
-  LdsSceneDims lds_dims = {0, 0, 0, 0};
+  LdsSceneDims lds_dims = {0, 0, 0, 0, 0};
   bool force_wq = false;              // RTX_TRACE_KERNEL=wq: workgroup-queue kernel (trace_wq.inc)
   bool wq_diag = false;               // RTX_TRACE_KERNEL=wq_diag: stage occupancy counters on stderr (never timed)
   bool wq_ok = false;                 // world fits k_trace_wq's 16-bit work items and LDS budget
@@ -487,17 +494,26 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
       } else if (ds->lds_ok && preset == 0 && !ds->force_wq && !ds->force_vote && !ds->force_persistent && !ds->force_stream && !ds->force_world && !ds->force_wave) {
         kernel_used = RTX_KERNEL_LDS;
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
-        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims);
+        // time-aware boxes when the scene has them and every ray's time lies inside the BVH's interval (camera.rs:69: [time1, time2))
+        const bool motion = ds->motion_ok && (double)cam->time1 >= ds->motion_t0 && (double)cam->time2 <= ds->motion_t1;
+        const bool ring = motion ? ds->motion_ring : ds->lds_ring;
+        const uint32_t ring_cap = motion ? ds->motion_ring_cap : ds->lds_ring_cap;
+        const LdsSceneDims dims = motion ? ds->motion_dims : ds->lds_dims;
+        const rt::real m_t0 = (rt::real)ds->motion_t0, m_inv = (rt::real)(1.0 / (ds->motion_t1 - ds->motion_t0));
+        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ring ? ring_cap : 0u, dims);
         uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
         uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
-#define LAUNCH_LDS(FEAT, RINGF)                                                                        \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
+#define LAUNCH_LDS2(FEAT, RINGF, MOTIONF)                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF, MOTIONF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ds->lds_ring_cap, (uint32_t)stack_levels, ds->lds_dims)
+                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, (uint32_t)stack_levels, dims, m_t0, m_inv)
+#define LAUNCH_LDS(FEAT, MOTIONF) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF); } else { LAUNCH_LDS2(FEAT, false, MOTIONF); } } while (0)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
-        if ((feat & ~P_STATIC_SPHERES) == 0) { if (ds->lds_ring) { LAUNCH_LDS(P_STATIC_SPHERES, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false); } }
-        else if (ds->lds_ring) { LAUNCH_LDS(P_SPHERES, true); } else { LAUNCH_LDS(P_SPHERES, false); }
+        if ((feat & ~P_STATIC_SPHERES) == 0) { LAUNCH_LDS(P_STATIC_SPHERES, false); }
+        else if (motion) { LAUNCH_LDS(P_SPHERES, true); }
+        else { LAUNCH_LDS(P_SPHERES, false); }
 #undef LAUNCH_LDS
+#undef LAUNCH_LDS2
 #ifdef RTX_EXPERIMENTAL_KERNELS
       } else if (ds->force_wq && ds->wq_ok && preset == 0) {
         kernel_used = RTX_KERNEL_WQ;
@@ -719,6 +735,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
     stats->passes = passes;
     stats->trace_kernel = kernel_used;
     stats->sample_buffer_bytes = need_samples;
+    stats->samples = (uint64_t)spp * npix;  // (pixel, sample) paths this call traced; the work counters below only in count mode
     if (COUNT) {
       rt::TraceCounters c;
       HIP_TRY(hipMemcpy(&c, ds->counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -749,7 +766,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
   rtx_status st;
 #define UP(field, vec) if ((st = upload_array(ds, fs.vec, &v.field)) != RTX_OK) { free_device_scene(ds); return st; }
   UP(spheres, spheres) UP(moving_spheres, moving_spheres) UP(rects, rects) UP(triangles, triangles)
-  UP(nodes, nodes) UP(nodes32, nodes32) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
+  UP(nodes, nodes) UP(nodes32, nodes32) UP(motion32, motion32) UP(refs, refs) UP(entries, entries) UP(top_level, top_level)
   UP(materials, materials) UP(textures, textures) UP(perlins, perlins) UP(images, images) UP(texels, texels)
   UP(top_box32, top_box32) UP(gravity_spheres, gravity_spheres) UP(gravity_y, gravity_y)
 #undef UP
@@ -964,7 +981,9 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       int lds_max = 0;
       (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
       if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size()};
+      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size(), LDSK_NODE_DWORDS};
+      ds->motion_dims = ds->lds_dims;
+      ds->motion_dims.node_dwords = LDSK_MOTION_NODE_DWORDS;
       const uint32_t levels = (uint32_t)fs.max_stack + 1u;
       const char* ck = getenv("RTX_CHUNK");
       if (ck && atoi(ck) >= 64 && atoi(ck) <= 65536) ds->lds_chunk = (uint32_t)atoi(ck);
@@ -978,19 +997,36 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
           }
         }
         if (!ds->lds_ok && ldsk_layout(levels, 0u, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
+        // the time-aware instantiation: the world's one BVH holds moving spheres and came with an interval
+        const rt::FlatEntry& be = fs.entries[fs.top_level[0]];
+        const char* mo = getenv("RTX_MOTION");
+        if (ds->lds_ok && !fs.motion32.empty() && (fs.features & rt::F_MOVING_SPHERE) && (double)be.f[0] < (double)be.f[1] && !(mo && atoi(mo) == 0)) {
+          ds->motion_t0 = (double)be.f[0]; ds->motion_t1 = (double)be.f[1];
+          // (a ring of fewer than 32 rays is worse than none: its refills run with that few lanes -- HEAD Book-1, ring of 16: 3137
+          // Msamples/s, no ring: 3774)
+          for (uint32_t cap : {64u, 48u, 32u}) {
+            if (want_ring && !ds->motion_ok && ldsk_layout(levels, cap, ds->motion_dims).total <= (uint32_t)lds_max) {
+              ds->motion_ok = true; ds->motion_ring = true; ds->motion_ring_cap = cap;
+            }
+          }
+          if (!ds->motion_ok && ldsk_layout(levels, 0u, ds->motion_dims).total <= (uint32_t)lds_max) { ds->motion_ok = true; ds->motion_ring = false; }
+        }
       }
       if (ds->lds_ok) {
         // the limit is a property of the function, not of this scene: raise it to the device maximum once, so that
         // scenes uploaded earlier (with other LDS sizes) keep launching
         const int bytes = lds_max;
-        hipError_t ae = hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_STATIC_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<P_STATIC_SPHERES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        hipError_t ae = hipSuccess;
+#define LDS_ATTR(FEAT, RINGF, MOTIONF) if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<FEAT, RINGF, MOTIONF>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+        LDS_ATTR(P_SPHERES, true, false); LDS_ATTR(P_SPHERES, false, false); LDS_ATTR(P_STATIC_SPHERES, true, false); LDS_ATTR(P_STATIC_SPHERES, false, false);
+        LDS_ATTR(P_SPHERES, true, true); LDS_ATTR(P_SPHERES, false, true);
+#undef LDS_ATTR
         if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
       }
-      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring of %u, %u B of LDS)\n", ds->lds_ok ? "on" : "off",
-                      ds->lds_ring ? ds->lds_ring_cap : 0u, ldsk_layout(levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims).total);
+      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring of %u, %u B of LDS); time-aware boxes %s (ring of %u, %u B)\n", ds->lds_ok ? "on" : "off",
+                      ds->lds_ring ? ds->lds_ring_cap : 0u, ldsk_layout(levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims).total,
+                      ds->motion_ok ? "on" : "off", ds->motion_ring ? ds->motion_ring_cap : 0u,
+                      ds->motion_ok ? ldsk_layout(levels, ds->motion_ring ? ds->motion_ring_cap : 0u, ds->motion_dims).total : 0u);
     }
 #ifdef RTX_EXPERIMENTAL_KERNELS
     ds->wq_diag = (k && strcmp(k, "wq_diag") == 0);

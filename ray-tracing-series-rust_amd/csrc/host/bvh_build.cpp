@@ -35,25 +35,25 @@ struct Box {
 };
 
 struct Builder {
-  const std::vector<double>& boxes;
+  const std::vector<double>& boxes;   // what the nodes store
+  const std::vector<double>& tboxes;  // what the topology is chosen by (the same boxes unless the caller has better ones)
   const BuildOptions& opt;
   std::vector<rt::FlatNode>* nodes;
   std::vector<uint32_t>& order;
   std::vector<double> centroids;  // 3 per primitive
   double sah = 0.0;
 
-  Builder(const std::vector<double>& b, const BuildOptions& o, std::vector<rt::FlatNode>* n,
+  Builder(const std::vector<double>& b, const std::vector<double>& tb, const BuildOptions& o, std::vector<rt::FlatNode>* n,
           std::vector<uint32_t>& ord)
-      : boxes(b), opt(o), nodes(n), order(ord) {}
+      : boxes(b), tboxes(tb), opt(o), nodes(n), order(ord) {}
 
   // Returns the child code for [begin, end) and its box; *depth = internal depth below.
   int32_t build(uint32_t begin, uint32_t end, Box* out_box, int32_t* depth) {
     uint32_t n = end - begin;
-    Box bb; bb.reset();
+    Box bb; bb.reset();   // stored box
     Box cb; cb.reset();
     for (uint32_t i = begin; i < end; ++i) {
-      const double* b = &boxes[6 * (size_t)order[i]];
-      bb.grow(b);
+      bb.grow(&boxes[6 * (size_t)order[i]]);
       const double* c = &centroids[3 * (size_t)order[i]];
       for (int a = 0; a < 3; ++a) { cb.mn[a] = std::min(cb.mn[a], c[a]); cb.mx[a] = std::max(cb.mx[a], c[a]); }
     }
@@ -79,7 +79,7 @@ struct Builder {
         int k = (int)((c - lo) * scale);
         if (k < 0) k = 0;
         if (k >= K) k = K - 1;
-        bin_box[k].grow(&boxes[6 * (size_t)order[i]]);
+        bin_box[k].grow(&tboxes[6 * (size_t)order[i]]);
         bin_cnt[k]++;
       }
       double right_area[64];
@@ -134,13 +134,23 @@ struct Builder {
     int32_t d0 = 0, d1 = 0;
     int32_t c0 = build(begin, mid, &b0, &d0);
     int32_t c1 = build(mid, end, &b1, &d1);
+    // A single primitive whose box is at least as big as everything beside it (Book-1's r = 1000 ground next to 483 small
+    // spheres) is asked FIRST by every ray, whatever its direction: one primitive test bounds the ray before the sibling
+    // subtree is walked (a downward ray otherwise walks the whole sphere field with an unbounded interval and meets the ground
+    // last), and because every ray of a wave takes it at the same step, that test runs with all lanes.  Encoded as split
+    // "axis" 3: the walkers pick the near child as (dir_neg >> axis) & 1 and dir_neg has three bits, so child 0 is always first.
+    if (opt.leaf_first) {
+      const bool l0 = rt::node_child_is_leaf(c0) && rt::leaf_count(c0) == 1, l1 = rt::node_child_is_leaf(c1) && rt::leaf_count(c1) == 1;
+      if (l1 && !l0 && b1.half_area() >= b0.half_area()) { std::swap(c0, c1); std::swap(b0, b1); axis_used = 3; }
+      else if (l0 && !l1 && b0.half_area() >= b1.half_area()) axis_used = 3;
+    }
     rt::FlatNode& nd = (*nodes)[idx];
     for (int a = 0; a < 3; ++a) {
       nd.bmin[0][a] = b0.mn[a]; nd.bmax[0][a] = b0.mx[a];
       nd.bmin[1][a] = b1.mn[a]; nd.bmax[1][a] = b1.mx[a];
     }
     nd.child[0] = c0; nd.child[1] = c1;
-    nd.pad[0] = axis_used;  // split axis: child 0 holds the lower centroids along it
+    nd.pad[0] = axis_used;  // split axis: child 0 holds the lower centroids along it (3: child 0 is always visited first)
     nd.pad[1] = 0;
     *depth = 1 + std::max(d0, d1);
     sah += bb.half_area();
@@ -152,7 +162,8 @@ struct Builder {
 
 int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
                   std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order, int32_t* depth,
-                  double* sah_cost) {
+                  double* sah_cost, const std::vector<double>* topology_boxes) {
+  const std::vector<double>& tboxes = (topology_boxes && topology_boxes->size() == boxes.size()) ? *topology_boxes : boxes;
   size_t n = boxes.size() / 6;
   order->resize(n);
   for (size_t i = 0; i < n; ++i) (*order)[i] = (uint32_t)i;
@@ -161,14 +172,14 @@ int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
   BuildOptions o = opt;
   if (o.max_leaf < 1) o.max_leaf = 1;
   if (o.max_leaf > 8) o.max_leaf = 8;
-  Builder b(boxes, o, nodes, *order);
+  Builder b(boxes, tboxes, o, nodes, *order);
   b.centroids.resize(3 * n);
   for (size_t i = 0; i < n; ++i)
-    for (int a = 0; a < 3; ++a) b.centroids[3 * i + a] = 0.5 * (boxes[6 * i + a] + boxes[6 * i + 3 + a]);
+    for (int a = 0; a < 3; ++a) b.centroids[3 * i + a] = 0.5 * (tboxes[6 * i + a] + tboxes[6 * i + 3 + a]);
   // Force at least one internal node even when n <= max_leaf, so the root is a node.
   BuildOptions forced = o;
   if ((int)n <= o.max_leaf) forced.max_leaf = (int)n - 1;
-  Builder bf(boxes, forced, nodes, *order);
+  Builder bf(boxes, tboxes, forced, nodes, *order);
   bf.centroids.swap(b.centroids);
   Box root_box;
   int32_t root = bf.build(0, (uint32_t)n, &root_box, depth);

@@ -15,6 +15,7 @@ struct FlatScene {
   std::vector<rt::FlatTriangle> triangles;
   std::vector<rt::FlatNode> nodes;
   std::vector<rt::FlatNode32> nodes32;  // same tree, boxes rounded outward to f32 (core/cull32.hpp)
+  std::vector<rt::FlatMotion32> motion32;  // time-aware boxes (empty unless a BVH holds MovingSpheres), parallel to nodes
   std::vector<rt::PrimRef> refs;
   std::vector<rt::FlatEntry> entries;
   std::vector<int32_t> top_level;
@@ -42,6 +43,7 @@ struct FlatScene {
     v.triangles = triangles.data();
     v.nodes = nodes.data();
     v.nodes32 = nodes32.data();
+    v.motion32 = motion32.empty() ? nullptr : motion32.data();
     v.refs = refs.data();
     v.entries = entries.data();
     v.top_level = top_level.data();
@@ -73,6 +75,12 @@ struct BuildOptions {
   // 1: BVHs of >= 1024 primitives are built on the current GPU (csrc/hip/lbvh.hip: Morton clusters + radix tree + refit)
   // instead of by the host SAH builder: same image, a tree of lower quality, built in milliseconds.
   int gpu_builder = 0;
+  // 1 (default): a single-primitive leaf whose box is at least as big as its sibling's is visited first by every ray
+  // (bvh_build.cpp); 0 restores the plain near-child-by-split-axis order for A/B (RTX_LEAF_FIRST=0).
+  int leaf_first = 1;
+  // 1 (default): a BVH that holds MovingSpheres is partitioned by its primitives' boxes at the middle of its time interval
+  // instead of by their boxes over the interval (flatten.cpp); RTX_MOTION_TOPOLOGY=0 for A/B.
+  int motion_topology = 1;
 };
 
 // Flatten `world` (any Hittable handle of `g`).  Returns false and sets *err when the graph
@@ -84,9 +92,12 @@ bool flatten_scene(const SceneGraph& g, int32_t world, const BuildOptions& opt, 
 // primitive.  Emits nodes (appended to *nodes, child indices absolute) and the
 // permutation `order` (slot -> input primitive).  Returns the root node index, or -1 if
 // n < 2 (the caller emits a GROUP instead).  *depth = the stack depth a walk needs.
+// topology_boxes (optional, same count): the boxes the splits are CHOSEN by, when they differ from the boxes the nodes store --
+// a BVH of moving spheres stores the reference's boxes over its whole time interval but is better partitioned by where the
+// spheres are at one instant (flatten.cpp).
 int32_t build_bvh(const std::vector<double>& boxes, const BuildOptions& opt,
                   std::vector<rt::FlatNode>* nodes, std::vector<uint32_t>* order, int32_t* depth,
-                  double* sah_cost);
+                  double* sah_cost, const std::vector<double>* topology_boxes = nullptr);
 // The GPU builder (csrc/hip/lbvh.hip).  Same contract; -1 with *err set when it cannot run (no GPU, allocation failure).
 int32_t build_bvh_gpu(const std::vector<double>& boxes, int max_leaf, std::vector<rt::FlatNode>* nodes,
                       std::vector<uint32_t>* order, int32_t* depth, double* device_ms, std::string* err);

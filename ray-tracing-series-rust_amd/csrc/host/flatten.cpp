@@ -29,7 +29,7 @@ size_t FlatScene::total_bytes() const {
          entries.size() * sizeof(rt::FlatEntry) + top_level.size() * sizeof(int32_t) +
          materials.size() * sizeof(rt::FlatMaterial) + textures.size() * sizeof(rt::FlatTexture) +
          perlins.size() * sizeof(rt::FlatPerlin) + images.size() * sizeof(rt::FlatImage) +
-         texels.size() * sizeof(double);
+         texels.size() * sizeof(double) + motion32.size() * sizeof(rt::FlatMotion32);
 }
 
 namespace {
@@ -125,12 +125,18 @@ struct Flattener {
     const GHittable& o = g.hittables[h];
     if (is_prim(o.kind)) { refs->push_back(emit_prim(h)); if (handles) handles->push_back(h); return true; }
     if (o.kind == H_RECT_PRISM) { emit_prism(o, refs); if (handles) handles->resize(refs->size(), -1); return true; }
-    if (o.kind == H_LIST) {
+    // A list or another BvhNode inside a BVH (or inside a transformed / medium list): BvhNode::from_list takes any Hittable
+    // (bvh.rs:85-93).  The closest hit over nested containers of plain primitives is the closest hit over the primitives, so the
+    // inner container dissolves into the outer one's primitive set and ONE tree is built over all of them (a BVH is a culling
+    // structure).  What the inner container's own order would decide -- an exact tie between two of its primitives -- follows
+    // the outer container's rule (later slot wins).
+    if (o.kind == H_LIST || o.kind == H_BVH) {
       for (int32_t c : o.children)
         if (!collect_prims(c, refs, depth + 1, handles)) return false;
       return true;
     }
-    return fail("unsupported nesting: only primitives, RectPrism and lists of those may sit inside a BVH or a transformed/medium list");
+    return fail("unsupported nesting: a Translate / RotateY / ConstantMedium INSIDE a BVH or inside a transformed or medium list "
+                "(an instanced sub-tree); primitives, RectPrisms, lists and BVHs of those may sit there");
   }
 
   // Reference bounding boxes (hit.rs bounding_box impls) of one flattened primitive.
@@ -245,7 +251,19 @@ struct Flattener {
           root = build_bvh_gpu(boxes, bo.max_leaf, &out.nodes, &order, &depth, &out.bvh_device_ms, &gerr);
           if (root < 0) { fail("GPU BVH builder: " + gerr); return -1; }
         } else {
-          root = build_bvh(boxes, bo, &out.nodes, &order, &depth, &out.sah_cost);
+          // A BVH that holds MovingSpheres: partition by where everything is at the MIDDLE of the interval.  The stored boxes (the
+          // reference's unions over the interval) of moving and static spheres overlap wherever the movers started; at one instant they
+          // are apart, SAH then keeps movers with movers, and the time-aware boxes of such subtrees (FlatMotion32) stay tight at every
+          // instant -- the lerp of a mixed subtree's end boxes spans start AND end.  Topology only: nothing a ray can see.
+          std::vector<double> mid_boxes;
+          bool movers = false;
+          for (rt::PrimRef r : refs) movers |= rt::primref_type(r) == rt::PRIM_MOVING_SPHERE;
+          if (movers && o.f[0] < o.f[1] && opt.motion_topology) {
+            mid_boxes.resize(boxes.size());
+            const double tm = 0.5 * (o.f[0] + o.f[1]);
+            for (size_t i = 0; i < refs.size(); ++i) prim_box(refs[i], tm, tm, &mid_boxes[6 * i]);
+          }
+          root = build_bvh(boxes, bo, &out.nodes, &order, &depth, &out.sah_cost, mid_boxes.empty() ? nullptr : &mid_boxes);
         }
         out.bvh_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
@@ -253,6 +271,7 @@ struct Flattener {
       e.a = root;
       e.b = (int32_t)out.refs.size();
       e.c = (int32_t)refs.size();
+      e.f[0] = o.f[0]; e.f[1] = o.f[1];  // BvhNode::from_list(list, time0, time1)
       // Triangles of this BVH are stored so that array order is leaf order: a leaf's triangles become neighbours in
       // memory, and for a pure mesh the slot of a reference is its triangle index minus a constant, which lets the
       // mesh kernels skip the reference fetch.  Only triangles nothing else refers to may be MOVED for that:
@@ -312,7 +331,7 @@ struct Flattener {
     int32_t cur = h;
     int nops = 0;
     while (g.hittables[cur].kind == H_TRANSLATE || g.hittables[cur].kind == H_ROTATE_Y) {
-      if (nops == RT_MAX_XFORM_OPS) { fail("more than 2 nested Translate/RotateY wrappers"); return -1; }
+      if (nops == RT_MAX_XFORM_OPS) { fail("more than " + std::to_string(RT_MAX_XFORM_OPS) + " nested Translate/RotateY wrappers around one object"); return -1; }
       const GHittable& w = g.hittables[cur];
       rt::FlatXformOp& op = e.ops[nops++];
       if (w.kind == H_TRANSLATE) { op.op = rt::XFORM_TRANSLATE; op.v[0] = w.f[0]; op.v[1] = w.f[1]; op.v[2] = w.f[2]; }
@@ -462,7 +481,82 @@ struct Flattener {
       m.child[0] = n.child[0]; m.child[1] = n.child[1];
       m.axis = n.pad[0]; m.pad = 0;
     }
+    build_motion_boxes();
     return true;
+  }
+
+  // ---- time-aware culling boxes (FlatMotion32, core/flat_types.hpp)
+  struct Box6 { double b[6]; };
+  // the box of `child` (a node index or a leaf code) of BVH entry e at the single instant t; fills boxes_at[node][c] on the way
+  Box6 motion_box_at(const rt::FlatEntry& e, int32_t child, double t, std::vector<Box6>* at) {
+    Box6 r;
+    for (int a = 0; a < 3; ++a) { r.b[a] = INFINITY; r.b[3 + a] = -INFINITY; }
+    auto grow = [&](const double* b) { for (int a = 0; a < 3; ++a) { r.b[a] = std::fmin(r.b[a], b[a]); r.b[3 + a] = std::fmax(r.b[3 + a], b[3 + a]); } };
+    if (rt::node_child_is_leaf(child)) {
+      const uint32_t f = rt::leaf_first(child), k = rt::leaf_count(child);
+      for (uint32_t i = 0; i < k; ++i) {
+        double b[6];
+        prim_box(out.refs[(size_t)e.b + f + i], t, t, b);
+        grow(b);
+      }
+      return r;
+    }
+    for (int c = 0; c < 2; ++c) {
+      const Box6 cb = motion_box_at(e, out.nodes[(size_t)child].child[c], t, at);
+      (*at)[2 * (size_t)child + c] = cb;
+      grow(cb.b);
+    }
+    return r;
+  }
+  void build_motion_boxes() {
+    out.motion32.clear();
+    bool any = false;
+    for (const rt::FlatEntry& e : out.entries) {
+      if (e.kind != rt::ENTRY_BVH || e.a < 0 || !(e.f[0] < e.f[1])) continue;
+      for (int32_t i = 0; i < e.c; ++i) any |= rt::primref_type(out.refs[(size_t)e.b + i]) == rt::PRIM_MOVING_SPHERE;
+    }
+    if (!any) return;
+    // every node starts as its static box (the reference's union over the interval, as in nodes32) with no slope
+    out.motion32.resize(out.nodes.size());
+    for (size_t i = 0; i < out.nodes.size(); ++i) {
+      rt::FlatMotion32& m = out.motion32[i];
+      memset(&m, 0, sizeof(m));
+      for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 3; ++a) { m.lo0[c][a] = out.nodes32[i].lo[c][a]; m.hi0[c][a] = out.nodes32[i].hi[c][a]; }
+    }
+    std::vector<Box6> at0(2 * out.nodes.size()), at1(2 * out.nodes.size());
+    for (const rt::FlatEntry& e : out.entries) {
+      if (e.kind != rt::ENTRY_BVH || e.a < 0 || !(e.f[0] < e.f[1])) continue;
+      bool moving = false, linear = true;
+      for (int32_t i = 0; i < e.c; ++i) {
+        const uint32_t ty = rt::primref_type(out.refs[(size_t)e.b + i]);
+        moving |= ty == rt::PRIM_MOVING_SPHERE;
+        linear &= ty != rt::PRIM_GRAVITY_SPHERE;  // a bouncing ball is not linear in time: such a BVH keeps its static boxes
+      }
+      if (!moving || !linear) continue;
+      std::vector<int32_t> todo{e.a};
+      (void)motion_box_at(e, e.a, e.f[0], &at0);
+      (void)motion_box_at(e, e.a, e.f[1], &at1);
+      while (!todo.empty()) {
+        const int32_t n = todo.back();
+        todo.pop_back();
+        rt::FlatMotion32& m = out.motion32[(size_t)n];
+        for (int c = 0; c < 2; ++c) {
+          const Box6 &b0 = at0[2 * (size_t)n + c], &b1 = at1[2 * (size_t)n + c];
+          for (int a = 0; a < 3; ++a) {
+            const double mag = std::fmax(std::fmax(std::fabs(b0.b[a]), std::fabs(b0.b[3 + a])), std::fmax(std::fabs(b1.b[a]), std::fabs(b1.b[3 + a])));
+            const double margin = mag * 0x1.0p-21 + 1e-30;
+            auto down = [](double x) { float f = (float)x; return (double)f > x ? std::nextafterf(f, -INFINITY) : f; };
+            auto up = [](double x) { float f = (float)x; return (double)f < x ? std::nextafterf(f, INFINITY) : f; };
+            const float lo_a = down(b0.b[a] - margin), lo_b = down(b1.b[a] - margin);
+            const float hi_a = up(b0.b[3 + a] + margin), hi_b = up(b1.b[3 + a] + margin);
+            m.lo0[c][a] = lo_a; m.dlo[c][a] = lo_b - lo_a;
+            m.hi0[c][a] = hi_a; m.dhi[c][a] = hi_b - hi_a;
+          }
+          if (!rt::node_child_is_leaf(out.nodes[(size_t)n].child[c])) todo.push_back(out.nodes[(size_t)n].child[c]);
+        }
+      }
+    }
   }
 };
 

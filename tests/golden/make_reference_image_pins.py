@@ -19,8 +19,13 @@ tests/test_reference_image_pins.py compares the CPU oracle (which this pins) and
 import json
 import os
 
+import sys
+
 import numpy as np
 from PIL import Image
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pin_estimators import CUBE_WINDOW, sphere_cube_extents  # noqa: E402  (shared with tests/test_reference_image_pins.py)
 
 REF = "/root/reference/images"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_image_pins.json")
@@ -60,7 +65,11 @@ def main():
         green_last, blue_first = wall_edges(d, row)
         edges.append({"row": row, "green_last_col": green_last, "blue_first_col": blue_first})
     regions = {"green_wall_upper": (20, 120, 5, 60), "backdrop_upper": (10, 60, 150, 450), "blue_wall_upper": (20, 120, 545, 595),
-               "green_wall_lower": (250, 360, 5, 80), "blue_wall_lower": (250, 360, 520, 595)}
+               "green_wall_lower": (250, 360, 5, 80), "blue_wall_lower": (250, 360, 520, 595),
+               # the floor, XzRect y = 5, Metal (0.3, 0.3, 0.3) fuzz 0.02 (world.rs:706-713): what it mirrors of the backdrop and the
+               # blue wall, lit by the (4, 4, 4) ceiling light (world.rs:739) and the mirror beside it (world.rs:714-721), far from
+               # the dragon and from its reflection (the stand-in mesh is not the dragon)
+               "floor_far_left": (172, 200, 100, 125), "floor_far_right": (172, 215, 445, 495), "floor_near_right": (300, 370, 410, 445)}
     black = 0
     while not d[black].any():
         black += 1
@@ -86,10 +95,14 @@ def main():
                # objects whose place is fixed and whose randomness averages out inside the region: the moving sphere
                # (MovingSphere, Lambertian (0.7, 0.3, 1), blurred over its 30 units of travel), the marble sphere (NoiseTexture 0.1:
                # the permutation tables are random, the mean is not), the blue subsurface sphere (glass ball + ConstantMedium 0.2)
-               "moving_sphere": (290, 370, 90, 190), "marble_sphere": (430, 560, 380, 500), "subsurface_sphere": (650, 800, 200, 340)}
+               "moving_sphere": (290, 370, 90, 190), "marble_sphere": (430, 560, 380, 500), "subsurface_sphere": (650, 800, 200, 340),
+               # the upper half of the fuzz-1.0 metal ball (Sphere (0, 150, 145) r = 50, Metal (0.8, 0.8, 0.9), world.rs:542-546;
+               # hit.rs:1066-1083): reflect + 1.0 * random_in_unit_sphere of a surface that faces the ceiling light
+               "fuzzy_metal_upper": (638, 678, 800, 870)}
     pins["book2"] = {
         "width": 1000, "height": 1000, "black_top_rows": black,
         "light_rows": light_rows,
+        "sphere_cube": sphere_cube_extents((((b + 0.5) / 256.0) ** 2)[CUBE_WINDOW[0]:CUBE_WINDOW[1], CUBE_WINDOW[2]:CUBE_WINDOW[3]]),
         "regions": {k: {"box": list(v), "linear_mean": linear_mean(b, v)} for k, v in regions.items()},
     }
 

@@ -77,9 +77,15 @@ def test_unsupported_shapes_are_reported_not_approximated(rtsr):
     b = rtsr.Builder(1)
     m = b.lambertian((0.5, 0.5, 0.5))
     s = b.sphere((0, 0, 0), 1.0, m)
-    deep = b.translate((1, 0, 0), b.translate((1, 0, 0), b.rotate_y(5.0, s)))  # three wrappers
+    deep = s
+    for k in range(5):  # five wrappers: one more than RT_MAX_XFORM_OPS (chains of up to four flatten: tests/test_nesting.py)
+        deep = b.translate((1, 0, 0), deep) if k % 2 else b.rotate_y(5.0, deep)
     with pytest.raises(rtsr.RtxError) as e:
         b.flatten(deep)
+    assert e.value.status == rtsr.RTX_EUNSUPPORTED
+    instanced = b.bvh_from_list(b.hittable_list([b.translate((1, 0, 0), s), s]), 0, 1)  # a wrapper INSIDE a BVH
+    with pytest.raises(rtsr.RtxError) as e:
+        b.flatten(instanced)
     assert e.value.status == rtsr.RTX_EUNSUPPORTED
     medium_in_bvh = b.bvh_from_list(b.hittable_list([b.constant_medium((1, 1, 1), 0.1, s), s]), 0, 1)
     with pytest.raises(rtsr.RtxError) as e:
