@@ -204,8 +204,15 @@ def valu_active_fraction(pmc, pmc_info, n_cu):
            "achieved": round(busy_clocks / t_s / 1e9, 1) if t_s > 0 else None,
            "peak": round(simds * kernel_clocks / t_s / 1e9, 1) if t_s > 0 else None}
     if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+        # The headline fraction is USEFUL issue: `busy` counts every clock the VALU is occupied, whatever the instruction does
+        # and however many of its 64 lanes are switched on; a path tracer's waves run with about half of them masked
+        # (divergent walks, rejection loops), so busy alone flatters the kernel.  frac = busy x lanes on.
+        res["busy"] = res["frac"]
         res["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
-        res["useful"] = round(res["frac"] * res["lane_utilisation"], 4)
+        res["useful"] = round(res["busy"] * res["lane_utilisation"], 4)
+        res["frac"] = res["useful"]
+        if res["achieved"] is not None:
+            res["achieved"] = round(res["achieved"] * res["lane_utilisation"], 1)
     if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAVES"):
         res["kernel_clocks_from_wave_cycles"] = round(4.0 * pmc["SQ_WAVE_CYCLES"] / pmc["SQ_WAVES"])
         res["wait_any_per_wave_cycle"] = round(pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"], 4)
@@ -213,67 +220,111 @@ def valu_active_fraction(pmc, pmc_info, n_cu):
     return res
 
 
-def valu_roofline(pmc, pmc_info, calib, n_cu):
-    """Cross-check of valu_active_fraction from instruction counts: sum_class(count x cost) / (SIMDs x kernel clocks),
-    cost of a class = the kernel's static opcode mix inside that class priced per opcode (an ESTIMATE: the dynamic mix
-    inside a hardware class is not observable; frac_lo / frac_hi bracket it)."""
-    mix_path = os.path.join(LIB_DIR, "kernel_mix.json")
-    cls_path = os.path.join(ROOT, "profiles", "opcode_classes.json")
-    need = ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"] + ["SQ_INSTS_VALU_" + c for c in VALU_CLASSES]
-    missing = [c for c in need if c not in pmc]
-    if missing or calib is None or not os.path.exists(mix_path) or not os.path.exists(cls_path):
-        return None, "missing: %s%s%s%s" % (",".join(missing), " calib" if calib is None else "",
-                                            "" if os.path.exists(mix_path) else " kernel_mix.json", "" if os.path.exists(cls_path) else " opcode_classes.json")
-    kernels = json.load(open(mix_path))["kernels"]
-    kname = pmc_info.get("kernel")
-    static = kernels.get(kname, {}).get("valu")
-    if not static:
-        return None, "kernel %r not in kernel_mix.json" % (kname,)
-    op_class = json.load(open(cls_path))["class_of"]
-    clk = calib["clocks_per_wave_inst"]
-    # nearest known opcode for the few the generator cannot benchmark (sdwa forms, v_cmpx): same mnemonic stem
-    def clocks_of(op):
-        if op in clk:
-            return clk[op]
-        stem = op.replace("_sdwa", "_e32").replace("_dpp", "_e32").replace("v_cmpx_", "v_cmp_")
-        for cand in (stem, stem.replace("_e32", "_e64"), stem.replace("_e64", "_e32"), stem.replace("_e32", "")):
-            if cand in clk:
-                return clk[cand]
+def build_flags():
+    try:
+        return json.load(open(os.path.join(LIB_DIR, "build_flags.json"))).get("trace_kernel_flags")
+    except Exception:  # noqa: BLE001
         return None
-    per_class = {}
-    for op, n in static.items():
-        c = clocks_of(op)
-        if c is None:
-            continue
-        cls = op_class.get(op) or op_class.get(op.replace("_sdwa", "_e32").replace("v_cmpx_", "v_cmp_")) or "OTHER"
-        d = per_class.setdefault(cls, {"n": 0, "clk": 0.0, "lo": 1e9, "hi": 0.0})
-        d["n"] += n; d["clk"] += n * c; d["lo"] = min(d["lo"], c); d["hi"] = max(d["hi"], c)
-    counts = {c: pmc["SQ_INSTS_VALU_" + c] for c in VALU_CLASSES}
-    counts["OTHER"] = max(0.0, pmc["SQ_INSTS_VALU"] - sum(counts.values()))
-    busy = busy_lo = busy_hi = 0.0
-    classes = {}
-    for cls, n_dyn in counts.items():
-        d = per_class.get(cls)
-        if d is None or d["n"] == 0:  # a class the static mix does not hold: price it like the cheapest f32 instruction
-            mean = lo = hi = min(clk.values())
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return "unknown"
+
+
+def c5_leg(rtsr, torch, dist, rank, world_size, use_gloo, spp):
+    """N > 1: one frame of BASELINE's scaling config (Book-1 final scene, 3840 x 2160) at a reduced, stated spp, sharded by rows
+    like the headline: per-rank render time (HIP events on the launch stream), the gather, the whole frame (max over ranks)."""
+    w5 = build_workload(rtsr, "c5", spp)
+    cam, cfg, width, height = w5["cam"], w5["cfg"], w5["width"], w5["height"]
+    scene = w5["flat"].upload()
+    shard = (rank, world_size, 1)
+    max_rows = max(rtsr.shard_rows(cfg, (r, world_size, 1)) for r in range(world_size))
+    buf = torch.zeros(max_rows * width * 3, dtype=torch.uint8, device="cuda")
+    host = torch.empty(buf.numel(), dtype=torch.uint8) if use_gloo else None
+    glist = [torch.empty_like(host if use_gloo else buf) for _ in range(world_size)] if rank == 0 else None
+    stream = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def frame(timed):
+        if timed:
+            ev[0].record(stream)
+        scene.render_device(cam, cfg, shard=shard, d_rgb8=buf.data_ptr(), stream=stream.cuda_stream)
+        if timed:
+            ev[1].record(stream)
+        if use_gloo:
+            host.copy_(buf)
+            dist.gather(host, gather_list=glist, dst=0)
         else:
-            mean, lo, hi = d["clk"] / d["n"], d["lo"], d["hi"]
-        busy += n_dyn * mean; busy_lo += n_dyn * lo; busy_hi += n_dyn * hi
-        classes[cls] = {"insts": round(n_dyn), "clocks_per_inst": round(mean, 2)}
-    kernel_clocks = pmc["GRBM_GUI_ACTIVE"] / N_XCD
-    simds = 4.0 * n_cu
-    t_s = (pmc_info.get("pmc_kernel_ms") or 0.0) * 1e-3
-    res = {"frac": round(busy / (simds * kernel_clocks), 4), "frac_lo": round(busy_lo / (simds * kernel_clocks), 4),
-           "frac_hi": round(busy_hi / (simds * kernel_clocks), 4), "issue_clocks_per_launch": round(busy),
-           "kernel_clocks": round(kernel_clocks), "simds": int(simds), "classes": classes,
-           "clock_ghz": round(kernel_clocks / t_s / 1e9, 3) if t_s > 0 else None,
-           "achieved": round(busy / t_s / 1e9, 1) if t_s > 0 else None, "peak": round(simds * kernel_clocks / t_s / 1e9, 1) if t_s > 0 else None}
-    if "SQ_THREAD_CYCLES_VALU" in pmc and pmc.get("SQ_ACTIVE_INST_VALU"):
-        res["lane_utilisation"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
-        res["useful"] = round(res["frac"] * res["lane_utilisation"], 4)
-    if "SQ_BUSY_CYCLES" in pmc:
-        res["kernel_clocks_sq_busy_over_32se"] = round(pmc["SQ_BUSY_CYCLES"] / 32.0)
-    return res, None
+            dist.gather(buf, gather_list=glist, dst=0)
+        if timed:
+            ev[2].record(stream)
+
+    frame(False)  # warm-up: scene tables into LDS / caches, RCCL channels for this message size
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mine = torch.tensor([elapsed * 1e3, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])], dtype=torch.float64,
+                        device="cpu" if use_gloo else "cuda")
+    every = [torch.zeros_like(mine) for _ in range(world_size)]
+    dist.all_gather(every, mine)
+    every = [[float(x) for x in t.cpu()] for t in every]
+    frame_ms = max(e[0] for e in every)
+    return {"workload": w5["desc"] + " -- run at %d spp" % spp, "value": round(width * height * spp / frame_ms / 1e3, 2), "unit": "Msamples/s",
+            "frame_ms": round(frame_ms, 3), "render_ms_per_rank": [round(e[1], 3) for e in every],
+            "gather_ms_per_rank": [round(e[2], 3) for e in every], "gathered_bytes": world_size * max_rows * width * 3,
+            "scaling": "strong (one frame cut into %d row-interleaved shards)" % world_size}
+
+
+def single_process(args):
+    """--single-process: N GPUs of this node from ONE process through rtx_multi_* (csrc/hip/multi.inc) -- what a Rust host that
+    replaces render_scene's band threads (world.rs:1198-1244) calls.  Steps are whole frames: launches on every device, ONE
+    ncclGather of the tone-mapped shards to the first device, rows back in order, copy to the host."""
+    import numpy as np
+    import torch  # first (see tests/conftest.py): only so that device pointers and HIP runtimes agree if anything else loads torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU render path")
+    rtsr = importlib.import_module("ray-tracing-series-rust_amd")
+    n = args.gpus
+    n_dev = torch.cuda.device_count()
+    if not args.same_device and n > n_dev:
+        raise SystemExit("--single-process --gpus %d: only %d device(s) visible (add --same-device for the one-GPU rehearsal)" % (n, n_dev))
+    out = {}
+    for name, spp in ((args.workload, args.spp), ("c5", args.c5_spp)):
+        w = build_workload(rtsr, name, spp)
+        ms = rtsr.MultiScene(w["flat"], n, device_ids=[0] * n if args.same_device else list(range(n)))
+        steps, warm = (args.steps, args.warmup) if name == args.workload else (1, 1)
+        for _ in range(warm):
+            ms.render(w["cam"], w["cfg"], want_accum=False)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            screen = ms.render(w["cam"], w["cfg"], want_accum=False)
+        elapsed = time.perf_counter() - t0
+        st = screen.stats
+        assert int(np.count_nonzero(screen.rgb8)) > 0
+        out[name] = {"workload": w["desc"] + ("" if spp == 0 else " -- run at %d spp" % w["spp"]),
+                     "value": round(float(w["width"]) * w["height"] * w["spp"] * steps / elapsed / 1e6, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+                     "render_ms_per_device": [round(st.render_ms[k], 3) for k in range(min(16, st.n_devices))], "gather_ms": round(st.gather_ms, 3),
+                     "gathered_bytes": int(st.gathered_bytes), "n_shards": st.n_shards, "n_devices": st.n_devices,
+                     "used_rccl": bool(st.used_rccl), "rccl_ranks_reported": st.rccl_ranks}
+        del ms
+    head = out[args.workload]
+    line = {"metric": "Msamples/s (pixels x spp) on Book-1 final scene" if args.workload in ("c1", "c2", "c5") else "Msamples/s (pixels x spp)",
+            "value": head["value"], "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": round(head["value"] / 1.4559, 1), "dtype": "f64", "data": "synthetic",
+            "config": {"workload": head["workload"], "mode": "single process, rtx_multi_* (C ABI)" + (", all shards on device 0 (rehearsal, no collective)" if args.same_device else ""),
+                       "frames_in_flight": 1, "sharding": "rows j %% %d == shard, one ncclGather of RGB8 per frame, host copy included" % n},
+            "roofline": None, "cpu_baseline": None, "multi": head, "c5": out.get("c5") if args.workload != "c5" else None}
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 # ------------------------------------------------------------------------------------------- main
@@ -298,11 +349,19 @@ def main():
                     "gather of frame k overlap the start of frame k + 1; 1: one frame at a time, e.g. under rocprofv3 --kernel-trace, whose "
                     "start stamp of a queued kernel is taken before its waves can run)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process through the C ABI's rtx_multi_* (one stream per "
+                    "device, ncclCommInitAll, one ncclGather per frame): the path a Rust host calls.  Launch WITHOUT torch.distributed.run")
+    ap.add_argument("--same-device", action="store_true", help="with --single-process: all N shards on device 0, copies instead of the "
+                    "collective (rehearsal of the sharding on a one-GPU box)")
+    ap.add_argument("--c5-spp", type=int, default=96, help="N > 1: spp of the extra C5 frame (3840x2160; BASELINE's scaling config at reduced spp)")
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH leaf size override (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="SAH bin count override (0 = library default)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+
+    if args.single_process:
+        return single_process(args)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -313,13 +372,13 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world_size, args.gpus))
 
     # ---- measurements that run in child processes come first: this process has not touched the GPU yet
-    calib = calib_err = None
     pmc, pmc_info = {}, {"errors": ["skipped"]}
     if rank == 0 and world_size == 1 and not args.no_pmc:
-        calib, calib_err = run_issue_calib(4)
         pmc, pmc_info = run_pmc_passes(args, PMC_PASSES, keep_dir=args.keep_pmc or None)
-        if calib is not None and args.keep_pmc:
-            json.dump(calib, open(os.path.join(args.keep_pmc, "issue_calib.json"), "w"))
+        if args.keep_pmc:  # the per-opcode issue costs behind DESIGN.md 5.1's check of the formula (lib/issue_calib)
+            calib, _ = run_issue_calib(4)
+            if calib is not None:
+                json.dump(calib, open(os.path.join(args.keep_pmc, "issue_calib.json"), "w"))
 
     import numpy as np
     import torch
@@ -421,6 +480,21 @@ def main():
 
     total_samples = float(width) * height * spp  # whole job, all ranks
     value = total_samples * args.steps / elapsed / 1e6
+    # one frame alone (no pipelining): what ONE rtx_render call delivers -- the reference's metric is one render
+    single_ms = None
+    if world_size == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            scene.render_device(cam, cfg, shard=shard, d_rgb8=bufs[0].data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+    c5 = None
+    if world_size > 1:
+        try:
+            c5 = c5_leg(rtsr, torch, dist, rank, world_size, use_gloo, args.c5_spp)
+        except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+            c5 = {"error": repr(e)[:300]}
 
     # ---- image assembled on rank 0 (also a sanity check of the gather)
     if rank == 0:
@@ -446,17 +520,14 @@ def main():
                 roofline.update(va)
                 roofline["kernel"] = pmc_info.get("kernel") or kernel_name
                 roofline["pmc_kernel_ms"] = pmc_info.get("pmc_kernel_ms")
-                roofline["formula"] = "frac = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x GRBM_GUI_ACTIVE / 8)"
+                roofline["formula"] = ("busy = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x GRBM_GUI_ACTIVE / 8); "
+                                       "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); frac = useful = busy x lane_utilisation")
+                if va.get("lane_utilisation"):
+                    # a work-based figure that must FALL when the algorithm gets better (frac alone cannot tell less work from idling):
+                    # lane-clocks of VALU issue spent per camera path
+                    roofline["lane_clocks_per_sample"] = round(va["busy_clocks_per_launch"] * 64.0 * va["lane_utilisation"] / (float(my_rows) * width * spp), 1)
                 roofline["source"] = ("measured in this run: %d rocprofv3 --pmc passes over a child process rendering the same workload" %
                                       len(pmc_info.get("passes", [])))
-            vr, err = valu_roofline(pmc, pmc_info, calib, n_cu)
-            if vr is not None:
-                # cross-check from instruction counts: every hardware class priced at its cheapest / dearest opcode of the
-                # shipped kernel (issue costs measured by lib/issue_calib in this run) must bracket the measured fraction
-                roofline["priced_from_instruction_counts"] = {"frac_lo": vr["frac_lo"], "frac_hi": vr["frac_hi"], "classes": vr["classes"],
-                                                              "note": "dynamic SQ_INSTS_VALU_* class counts x per-opcode issue clocks; the mix inside a class is not observable, hence a bracket"}
-            elif va is None:
-                roofline["valu_error"] = err
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KB) under-reports wide reads 2x on gfx950; WRITE_SIZE (KB) is exact
                 hbm_bytes = pmc["FETCH_SIZE"] * 1024.0 * 2.0 + pmc["WRITE_SIZE"] * 1024.0
@@ -469,8 +540,6 @@ def main():
                                    "insts_per_launch": round(pmc.get("SQ_INSTS_LDS", 0.0))}
         if pmc_info.get("errors") and pmc_info["errors"] != ["skipped"]:
             roofline["pmc_errors"] = pmc_info["errors"][:3]
-        if calib_err:
-            roofline["calib_error"] = calib_err
         # -- SURVEY 8(d) algorithmic bytes (a model figure: the scene is on chip, so it exceeds what HBM could deliver)
         if not args.no_count:
             count_spp = min(spp, args.count_spp)
@@ -543,7 +612,7 @@ def main():
             t0 = time.perf_counter()
             orc.o1_render(b.graph_ptr(), world, cam, ccfg, height, threads=cores)
             dt = time.perf_counter() - t0
-            cpu = {"value": round(width * height * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(width * height * cpu_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
                    "sample": "%dx%d at %d spp (same scene, camera, depth, seeds), oracle O1 with %d row-band threads, %.1f s" % (
                        width, height, cpu_spp, cores, dt)}
             # the README's setting (10 threads, README.md:23), on a smaller sample of the same workload
@@ -567,6 +636,13 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_cpu_published": {"value": 1.4559, "unit": "Msamples/s", "source": "README.md:23, 10 threads, CPU unstated"},
         }
+        if single_ms is not None:
+            out["single_frame"] = {"ms": round(single_ms, 3), "value": round(total_samples / single_ms / 1e3, 2), "unit": "Msamples/s",
+                                   "note": "one frame at a time, launch to last byte (what one rtx_render_device call takes); `value` above pipelines %d frames" % N_PIPE}
+        if world_size > 1:
+            out["ranks_reported"] = {"torch.distributed": dist.get_world_size(), "backend": dist.get_backend()}
+            out["c5"] = c5
+        out["build_flags"] = build_flags()
         if extras is not None:
             out["other_workloads"] = extras
         if emulated:

@@ -254,7 +254,8 @@ typedef struct RtxMultiStats {
   double render_ms_max;   /* slowest device, first launch to end of tone map (HIP events) */
   double total_ms;        /* host wall time of the call: launches + gather + reorder + copy to the host */
   uint64_t gathered_bytes;
-  int32_t n_shards, n_devices, used_rccl, reserved;
+  int32_t n_shards, n_devices, used_rccl;
+  int32_t rccl_ranks;     /* ncclCommCount of the communicator the gather ran on (0 without one) */
   double gather_ms;       /* on the first device's stream: end of its own shard -> every shard gathered and put in row order
                              (includes waiting for the slowest peer) */
   double render_ms[16];   /* per device (first 16), as render_ms_max */

@@ -77,7 +77,7 @@ class RtxRenderStats(C.Structure):
 
 class RtxMultiStats(C.Structure):
     _fields_ = [("render_ms_max", C.c_double), ("total_ms", C.c_double), ("gathered_bytes", C.c_uint64),
-                ("n_shards", C.c_int32), ("n_devices", C.c_int32), ("used_rccl", C.c_int32), ("reserved", C.c_int32),
+                ("n_shards", C.c_int32), ("n_devices", C.c_int32), ("used_rccl", C.c_int32), ("rccl_ranks", C.c_int32),
                 ("gather_ms", C.c_double), ("render_ms", C.c_double * 16)]
 
 

@@ -191,3 +191,28 @@ def test_ply_model_through_the_device(rtsr, orc, tmp_path, binary):
     a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=8)
     assert np.array_equal(screen.accum, a1) and np.array_equal(screen.rgb8, r1)
     assert screen.accum.std() > 0.01
+
+
+def test_ppm_image_texture_on_the_device(rtsr, orc, tmp_path):
+    """Image::from_ppm (texture.rs:95-99 -> Screen::from_ppm_p3, screen.rs:61-95) feeding an Image texture on the HIP path: a P3
+    file written here, read by rtx_image_from_ppm, wrapped on a sphere and on a rectangle (sphere uv from the outward normal,
+    hit.rs:226-236; rectangle uv, hit.rs:486-489), rendered by the device and by the literal oracle O1."""
+    w, h = 64, 32
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(xx * 4) % 256, (yy * 8) % 256, ((xx // 8 + yy // 8) % 2) * 255], axis=2).astype(np.uint8)
+    path = tmp_path / "tex.ppm"
+    path.write_text("P3\n%d %d\n255\n" % (w, h) + "".join("%d %d %d\n" % tuple(p) for row in rgb for p in row))
+    b = rtsr.Builder(1)
+    tex = b.image_from_ppm(str(path))
+    world = b.hittable_list([b.sphere((0.0, 0.0, 0.0), 2.0, b.lambertian(tex)),
+                             b.xy_rect(-6.0, 6.0, -3.0, 3.0, -2.5, b.lambertian(tex)),
+                             b.sphere((0.0, 6.0, 4.0), 1.5, b.diffuse_light((6.0, 6.0, 6.0)))])
+    cam = rtsr.Camera.new((3.0, 1.0, 9.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.5, 0.0, 9.0, 0.0, 1.0)
+    cfg = rtsr.Config.new(1.5, 192, 16, 12, 4, seed=4, background=(0.3, 0.3, 0.4))
+    hgt = rtsr.image_height(cfg)
+    flat = b.flatten(world)
+    assert flat.info()["n_texels"] == w * h and flat.info()["n_images"] == 1
+    screen = flat.upload().render(cam, cfg)
+    a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, hgt, threads=16)
+    assert np.array_equal(screen.accum, a1) and np.array_equal(screen.rgb8, r1)
+    assert len(np.unique(screen.rgb8.reshape(-1, 3), axis=0)) > 500  # the picture is on the surfaces

@@ -61,3 +61,21 @@ def test_multi_errors(rtsr):
     if n_dev >= 1:
         with pytest.raises(rtsr.RtxError):
             rtsr.MultiScene(flat, 3, device_ids=[0, 0, n_dev])
+
+
+def test_two_distinct_devices_equal_rtx_render(rtsr):
+    """N > 1 DISTINCT devices: ncclCommInitAll over two GPUs, the grouped ncclGather with a root-only receive buffer, one stream and
+    one event pair per device.  Needs two GPUs in this process (the round's box has one: skipped there, and the path stays
+    'parity unpinned on hardware' until a node runs it); frees both scenes afterwards."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: rtx_multi over distinct devices cannot run here")
+    b, world, cam, cfg, flat = _setup(rtsr, 100, 200, 1.5, 16)
+    single = flat.upload().render(cam, cfg)
+    multi = rtsr.MultiScene(flat, 2, device_ids=[0, 1])
+    screen = multi.render(cam, cfg)
+    assert screen.stats.used_rccl == 1 and screen.stats.n_devices == 2 and screen.stats.rccl_ranks in (0, 2)
+    assert np.array_equal(screen.rgb8, single.rgb8) and np.array_equal(screen.accum, single.accum)
+    again = multi.render(cam, cfg, want_accum=False)  # the communicator and the buffers are reused
+    assert np.array_equal(again.rgb8, single.rgb8)
+    del multi

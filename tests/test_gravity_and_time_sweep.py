@@ -132,3 +132,33 @@ def test_time_sweep_frames_on_a_resident_scene(rtsr, orc, tmp_path):
     assert not np.array_equal(frames[0], frames[2])  # the balls moved between frames
     with pytest.raises(rtsr.RtxError):  # t0 >= t1: gen_range(t0..t1) panics in the reference
         scene.render_scene_with_time(1.0, 1.0, str(tmp_path / "x.ppm"))
+
+
+@pytest.mark.gpu
+def test_time_sweep_frame_at_the_reference_size(rtsr, orc, tmp_path):
+    """One frame of render_scene_with_time AS THE REFERENCE RENDERS IT (world.rs:1252-1275): 500 x 500, 500 spp, depth 50, 11 row
+    bands, on scene 8 (466 GravitySpheres, world.rs:169-244) kept resident -- 125 million paths through rtx_render_scene_with_time
+    with no overrides.  Checked: the PPM's shape, the 5 rows the band split drops, three of its rows against the literal oracle O1
+    at the same 500 spp, and that the second frame of the sweep differs (the balls fell)."""
+    b = rtsr.Builder(1)
+    world, _, bg = b.get_world_cam(rtsr.SCENE_RANDOM_MOVING)
+    flat = b.flatten(world)
+    scene = flat.upload()
+    t0, t1 = 0.2, 0.3
+    path = str(tmp_path / "frame.ppm")
+    scene.render_scene_with_time(t0, t1, path, row_chunk_compat=True)
+    with open(path) as f:
+        assert f.readline().strip() == "P3" and f.readline().split() == ["500", "500"] and f.readline().strip() == "255"
+        px = np.loadtxt(f, dtype=np.int64).reshape(500, 500, 3)
+    assert not px[:5].any() and px[5].any()  # 500 / 11 = 45 rows per band: rows 495..499 (the file's first five) are never rendered
+    cam = rtsr.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, 1.0, 0.1, 10.0, t0, t1)
+    cfg = rtsr.Config.new(1.0, 500, 500, 50, 11, seed=1, background=(0.7, 0.8, 1.0), row_chunk_compat=True)
+    for top_row in (120, 300, 430):  # sky + balls, the big spheres, the ground
+        acc = orc.o1_render_window(b.graph_ptr(), world, cam, cfg, 500, (top_row, top_row + 1, 0, 500), threads=16)
+        want = np.array([orc.tone_map("o1", p, 500) for p in acc[0]])  # get_normalized_color, vec3.rs:89-107
+        assert np.array_equal(px[top_row], want), top_row
+    path2 = str(tmp_path / "frame2.ppm")
+    over = rtsr.Config.new(1.0, 500, 8, 50, 11, seed=1)
+    scene.render_scene_with_time(1.2, 1.3, path2, row_chunk_compat=True, overrides=over)
+    scene.render_scene_with_time(t0, t1, path, row_chunk_compat=True, overrides=over)
+    assert open(path2).read() != open(path).read()

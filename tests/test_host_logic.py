@@ -189,3 +189,29 @@ def test_binary_ply_matches_ascii(rtsr, orc, tmp_path):
     bad.write_bytes(header + body[:-5])
     with pytest.raises(rtsr.RtxError):
         b.triangle_model(str(bad), 1.0)
+
+
+def test_time_aware_boxes_contain_their_spheres_and_cannot_be_seen(rtsr, orc):
+    """FlatMotion32 (core/flat_types.hpp): for BVHs that hold MovingSpheres every child box, evaluated in f32 exactly as
+    k_trace_lds evaluates it, contains every sphere below it at 24 instants of the BVH's interval; the CPU restatement of
+    k_trace_lds's walk over those boxes renders the frame of the plain oracle bit for bit and visits far fewer nodes than the
+    same walk over the reference's boxes (unions over the whole interval, hit.rs:317-327)."""
+    for sid, expect_motion in ((13, True), (7, True), (100, False), (6, False)):
+        b = rtsr.Builder(1)
+        world, cam, bg = b.get_world_cam(sid)
+        flat = b.flatten(world)
+        rc, n = orc.audit_motion(flat.arrays_ptr(), 24)
+        assert rc == 0, (sid, rc)
+        assert (n > 0) == expect_motion, (sid, n)
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(13)   # Book-1 as gen_random_scene builds it at HEAD: 80 % of the small spheres rise 5 units
+    cfg = rtsr.Config.new(16.0 / 9.0, 96, 4, 50, 4, seed=3, background=bg)
+    h = rtsr.image_height(cfg)
+    flat = b.flatten(world)
+    ref, _ = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=8)
+    static, c_static = orc.lds_walk_render(flat.arrays_ptr(), cam, cfg, h, use_motion=False, threads=8)
+    moving, c_moving = orc.lds_walk_render(flat.arrays_ptr(), cam, cfg, h, use_motion=True, threads=8)
+    assert np.array_equal(static, ref) and np.array_equal(moving, ref)
+    assert c_static["rays"] == c_moving["rays"]
+    assert c_moving["node_visits"] < 0.65 * c_static["node_visits"], (c_static, c_moving)
+    assert c_moving["prim_tests"] < 0.5 * c_static["prim_tests"], (c_static, c_moving)
