@@ -404,3 +404,95 @@ extern "C" int oracle_lds_walk_render(const void* flat, const OracleCamera* cam,
   }
   return 0;
 }
+
+// Diagnostic: how many steps a 4-wide collapse of the world's one BVH would take (children sorted by entry distance, nearest
+// first, as walk_node_step4 does), for the same paths as oracle_lds_walk_render: counts[0] = rays, [1] = wide node steps,
+// [2] = primitive tests, [3] = child boxes tested.  The collapse opens the child with the largest area until four slots are used.
+extern "C" int oracle_wide_walk_stats(const void* flat, const OracleCamera* cam, const OracleConfig* cfg, int32_t row_stride, uint64_t counts[4]) {
+  if (!flat || !cam || !cfg || row_stride <= 0) return 1;
+  const rtx::FlatScene& fs = *(const rtx::FlatScene*)flat;
+  if (fs.top_level.size() != 1 || fs.entries[fs.top_level[0]].kind != rt::ENTRY_BVH) return 2;
+  const rt::FlatEntry& be = fs.entries[fs.top_level[0]];
+  struct W { float lo[4][3], hi[4][3]; int32_t child[4]; int n; };
+  std::vector<W> wide(fs.nodes.size());
+  {
+    std::vector<int32_t> todo{be.a};
+    while (!todo.empty()) {
+      const int32_t n = todo.back(); todo.pop_back();
+      struct S { int32_t code; const float *lo, *hi; double area; };
+      auto slot = [&](int32_t node, int c) {
+        const rt::FlatNode32& q = fs.nodes32[(size_t)node];
+        const double dx = (double)q.hi[c][0] - q.lo[c][0], dy = (double)q.hi[c][1] - q.lo[c][1], dz = (double)q.hi[c][2] - q.lo[c][2];
+        return S{q.child[c], q.lo[c], q.hi[c], dx * dy + dy * dz + dz * dx};
+      };
+      S sl[4] = {slot(n, 0), slot(n, 1), {}, {}};
+      int ns = 2;
+      while (ns < 4) {
+        int bi = -1; double ba = -1.0;
+        for (int k = 0; k < ns; ++k) if (sl[k].code >= 0 && sl[k].area > ba) { ba = sl[k].area; bi = k; }
+        if (bi < 0) break;
+        const int32_t open = sl[bi].code;
+        sl[bi] = slot(open, 0); sl[ns++] = slot(open, 1);
+      }
+      W& w = wide[(size_t)n];
+      w.n = ns;
+      for (int k = 0; k < ns; ++k) {
+        for (int a = 0; a < 3; ++a) { w.lo[k][a] = sl[k].lo[a]; w.hi[k][a] = sl[k].hi[a]; }
+        w.child[k] = sl[k].code;
+        if (sl[k].code >= 0) todo.push_back(sl[k].code);
+      }
+    }
+  }
+  const rt::SceneView sv = fs.view();
+  const rt::RenderParams rp = make_params(cam, cfg);
+  const int32_t w = rp.image_width, h = rp.image_height;
+  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  std::vector<int32_t> stack(256);
+  for (int32_t j = 0; j < h; j += row_stride)
+    for (int32_t i = 0; i < w; ++i)
+      for (int32_t s = 0; s < rp.samples_per_pixel; ++s) {
+        rt::PathState ps;
+        rt::path_begin(rp, (uint32_t)i, (uint32_t)j, (uint32_t)s, &ps);
+        for (;;) {
+          if (rt::path_bounce_begin(&ps)) break;
+          ++c0;
+          const rt::Ray32 q = rt::make_ray32(ps.ray, rt::ray_t_min(ps.ray));
+          float t_max32 = __builtin_huge_valf();
+          rt::Closest best; best.t = RT_INFINITY; best.hit = false; best.ref = 0; best.order = 0;
+          int n_stack = 0;
+          int32_t cur = be.a;
+          for (;;) {
+            if (cur >= 0) {
+              ++c1;
+              const W& nd = wide[(size_t)cur];
+              struct H { float key; int32_t code; } hits[4];
+              int nh = 0;
+              for (int k = 0; k < nd.n; ++k) {
+                ++c3;
+                if (!rt::cull32_may_hit(nd.lo[k], nd.hi[k], q, t_max32)) continue;
+                // entry distance as the sort key
+                float tn = q.t_min;
+                const float a0 = std::fmin(std::fmaf(nd.lo[k][0], q.ix, -q.oix), std::fmaf(nd.hi[k][0], q.ix, -q.oix));
+                const float a1 = std::fmin(std::fmaf(nd.lo[k][1], q.iy, -q.oiy), std::fmaf(nd.hi[k][1], q.iy, -q.oiy));
+                const float a2 = std::fmin(std::fmaf(nd.lo[k][2], q.iz, -q.oiz), std::fmaf(nd.hi[k][2], q.iz, -q.oiz));
+                tn = std::fmax(tn, std::fmax(a0, std::fmax(a1, a2)));
+                hits[nh++] = H{tn, nd.child[k]};
+              }
+              std::stable_sort(hits, hits + nh, [](const H& x, const H& y) { return x.key > y.key; });  // farthest first: nearest ends on top
+              for (int k = 0; k < nh; ++k) stack[(size_t)n_stack++] = hits[k].code;
+              if (n_stack > 0) cur = stack[(size_t)--n_stack]; else break;
+            } else {
+              const uint32_t f = rt::leaf_first(cur), k = rt::leaf_count(cur);
+              for (uint32_t x = 0; x < k; ++x) { ++c2; rt::offer_prim<rt::F_ALL, false>(sv, fs.refs[(size_t)be.b + f + x], f + x, ps.ray, rt::ray_t_min(ps.ray), &best, nullptr); }
+              t_max32 = rt::cull_round_up(best.t);
+              if (n_stack > 0) cur = stack[(size_t)--n_stack]; else break;
+            }
+          }
+          rt::HitRecord rec;
+          if (best.hit) rt::prim_finalize<rt::F_ALL>(sv, best.ref, ps.ray, best.t, &rec);
+          if (rt::path_bounce_end<rt::F_ALL, false>(sv, rp, &ps, best.hit, rec, nullptr)) break;
+        }
+      }
+  counts[0] = c0; counts[1] = c1; counts[2] = c2; counts[3] = c3;
+  return 0;
+}

@@ -107,6 +107,19 @@ RT_HD bool cull32_may_hit_nf(float nx, float fx, float ny, float fy, float nz, f
   return !(tn - tf > __builtin_fmaf(__builtin_fabsf(tn) + __builtin_fabsf(tf), 0x1.0p-21f, q.err2));
 }
 
+// The same verdict for queries whose t_min is POSITIVE (every ray_color query: world.hit(r, 0.001, inf), world.rs:77 -- not the
+// second boundary query of a medium), written so that it costs three instructions after the min / max: with tn >= t_min > 0,
+//     tn - tf > (tn + |tf|) e + 2E   <=>   tn (1 - e) - 2E  >  tf + |tf| e            (e = 2^-21; 1 - e is an exact f32)
+// one fma per side (|tf| is a free source modifier) and one compare; the roundings of the two fmas are of the size of the one
+// the difference had (<= u (tn + |tf|)), inside the same slack.
+RT_HD bool cull32_may_hit_nf_pos(float nx, float fx, float ny, float fy, float nz, float fz, const Ray32& q, float t_max32) {
+  const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx, q.ix, -q.oix), __builtin_fmaf(ny, q.iy, -q.oiy)),
+                                                   __builtin_fmaf(nz, q.iz, -q.oiz)), q.t_min);
+  const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(fx, q.ix, -q.oix), __builtin_fmaf(fy, q.iy, -q.oiy)),
+                                                   __builtin_fmaf(fz, q.iz, -q.oiz)), t_max32);
+  return !(__builtin_fmaf(tn, 1.0f - 0x1.0p-21f, -q.err2) > __builtin_fmaf(__builtin_fabsf(tf), 0x1.0p-21f, tf));
+}
+
 // Both children of a node at once.  Same arithmetic as two cull32_may_hit calls; on the device the twelve plane
 // fmas are written as four 2-wide ones (x and y of a plane set) plus four scalar ones for z, so that the pairs
 // issue as v_pk_fma_f32 -- an fma gives the same value whichever instruction carries it.

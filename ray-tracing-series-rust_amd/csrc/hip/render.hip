@@ -99,6 +99,11 @@ struct DeviceScene {
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   // the same plan for the time-aware instantiation (bigger node records: its own ring size); chosen per render, when the camera's
   // shutter lies inside the BVH's time interval [motion_t0, motion_t1] (RTX_MOTION=0 turns it off)
+  // ... and for the 4-wide collapse of the tree (static worlds; RTX_LDS_WIDE=0 turns it off): its node image, ring and stack depth
+  bool w4_ok = false, w4_ring = false;
+  uint32_t w4_ring_cap = 0, w4_levels = 0;
+  LdsSceneDims w4_dims = {0, 0, 0, 0, 0};
+  const uint32_t* w4_image = nullptr;
   bool motion_ok = false, motion_ring = false;
   uint32_t motion_ring_cap = 0;
   LdsSceneDims motion_dims = {0, 0, 0, 0, 0};
@@ -496,22 +501,25 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         HIP_TRY(hipMemsetAsync(ds->work_counter, 0, sizeof(unsigned int), stream));
         // time-aware boxes when the scene has them and every ray's time lies inside the BVH's interval (camera.rs:69: [time1, time2))
         const bool motion = ds->motion_ok && (double)cam->time1 >= ds->motion_t0 && (double)cam->time2 <= ds->motion_t1;
-        const bool ring = motion ? ds->motion_ring : ds->lds_ring;
-        const uint32_t ring_cap = motion ? ds->motion_ring_cap : ds->lds_ring_cap;
-        const LdsSceneDims dims = motion ? ds->motion_dims : ds->lds_dims;
+        const bool w4 = !motion && ds->w4_ok;
+        const bool ring = motion ? ds->motion_ring : (w4 ? ds->w4_ring : ds->lds_ring);
+        const uint32_t ring_cap = motion ? ds->motion_ring_cap : (w4 ? ds->w4_ring_cap : ds->lds_ring_cap);
+        const LdsSceneDims dims = motion ? ds->motion_dims : (w4 ? ds->w4_dims : ds->lds_dims);
+        const uint32_t lds_levels = w4 ? ds->w4_levels : (uint32_t)stack_levels;
         const rt::real m_t0 = (rt::real)ds->motion_t0, m_inv = (rt::real)(1.0 / (ds->motion_t1 - ds->motion_t0));
-        const LdsKernelLayout L = ldsk_layout((uint32_t)stack_levels, ring ? ring_cap : 0u, dims);
+        const LdsKernelLayout L = ldsk_layout(lds_levels, ring ? ring_cap : 0u, dims);
         uint64_t want = ((uint64_t)total + LDSK_BLOCK - 1) / LDSK_BLOCK;
         uint32_t grid = (uint32_t)(want < (uint64_t)ds->n_cu ? want : (uint64_t)ds->n_cu);
-#define LAUNCH_LDS2(FEAT, RINGF, MOTIONF)                                                                        \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF, MOTIONF>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
+#define LAUNCH_LDS2(FEAT, RINGF, MOTIONF, W4F)                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF, MOTIONF, W4F>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, (uint32_t)stack_levels, dims, m_t0, m_inv)
-#define LAUNCH_LDS(FEAT, MOTIONF) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF); } else { LAUNCH_LDS2(FEAT, false, MOTIONF); } } while (0)
+                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, lds_levels, dims, m_t0, m_inv, ds->w4_image)
+#define LAUNCH_LDS(FEAT, MOTIONF, W4F) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF, W4F); } else { LAUNCH_LDS2(FEAT, false, MOTIONF, W4F); } } while (0)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
-        if ((feat & ~P_STATIC_SPHERES) == 0) { LAUNCH_LDS(P_STATIC_SPHERES, false); }
-        else if (motion) { LAUNCH_LDS(P_SPHERES, true); }
-        else { LAUNCH_LDS(P_SPHERES, false); }
+        if ((feat & ~P_STATIC_SPHERES) == 0) { if (w4) { LAUNCH_LDS(P_STATIC_SPHERES, false, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false, false); } }
+        else if (motion) { LAUNCH_LDS(P_SPHERES, true, false); }
+        else if (w4) { LAUNCH_LDS(P_SPHERES, false, true); }
+        else { LAUNCH_LDS(P_SPHERES, false, false); }
 #undef LAUNCH_LDS
 #undef LAUNCH_LDS2
 #ifdef RTX_EXPERIMENTAL_KERNELS
@@ -997,8 +1005,35 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
           }
         }
         if (!ds->lds_ok && ldsk_layout(levels, 0u, ds->lds_dims).total <= (uint32_t)lds_max) { ds->lds_ok = true; ds->lds_ring = false; }
-        // the time-aware instantiation: the world's one BVH holds moving spheres and came with an interval
         const rt::FlatEntry& be = fs.entries[fs.top_level[0]];
+        // the 4-wide collapse of the tree
+        // Measured on C2 and NOT the default: 236 wide nodes, 5.05 steps per ray against 10.6, bit-identical -- and 2.4 % slower
+        // (5997 against 6143 Msamples/s): sorting four children by entry distance and four conditional stack writes make a wide
+        // step ~2.3 x a binary one, whose near / far order comes for free out of the address.  Kept as the A/B partner (RTX_LDS_WIDE=1).
+        const char* lw = getenv("RTX_LDS_WIDE");
+        if (ds->lds_ok && lw && atoi(lw) != 0) {
+          std::vector<uint32_t> image;
+          uint32_t n_wide = 0;
+          const uint32_t wl = build_lds_wide_image(fs.nodes, be.a, &image, &n_wide);
+          if (wl > 0u) {
+            ds->w4_dims = ds->lds_dims;
+            ds->w4_dims.n_nodes = n_wide;
+            ds->w4_dims.node_dwords = LDSK_WIDE_NODE_DWORDS;
+            ds->w4_levels = wl;
+            for (uint32_t cap : {64u, 48u, 32u}) {
+              if (want_ring && !ds->w4_ok && ldsk_layout(wl, cap, ds->w4_dims).total <= (uint32_t)lds_max) {
+                ds->w4_ok = true; ds->w4_ring = true; ds->w4_ring_cap = cap;
+              }
+            }
+            if (!ds->w4_ok && ldsk_layout(wl, 0u, ds->w4_dims).total <= (uint32_t)lds_max) { ds->w4_ok = true; ds->w4_ring = false; }
+            if (ds->w4_ok) {
+              const uint32_t* dptr = nullptr;
+              if ((st = upload_array(ds, image, &dptr)) != RTX_OK) { free_device_scene(ds); return st; }
+              ds->w4_image = dptr;
+            }
+          }
+        }
+        // the time-aware instantiation: the world's one BVH holds moving spheres and came with an interval
         const char* mo = getenv("RTX_MOTION");
         if (ds->lds_ok && !fs.motion32.empty() && (fs.features & rt::F_MOVING_SPHERE) && (double)be.f[0] < (double)be.f[1] && !(mo && atoi(mo) == 0)) {
           ds->motion_t0 = (double)be.f[0]; ds->motion_t1 = (double)be.f[1];
@@ -1017,12 +1052,15 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         // scenes uploaded earlier (with other LDS sizes) keep launching
         const int bytes = lds_max;
         hipError_t ae = hipSuccess;
-#define LDS_ATTR(FEAT, RINGF, MOTIONF) if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<FEAT, RINGF, MOTIONF>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-        LDS_ATTR(P_SPHERES, true, false); LDS_ATTR(P_SPHERES, false, false); LDS_ATTR(P_STATIC_SPHERES, true, false); LDS_ATTR(P_STATIC_SPHERES, false, false);
-        LDS_ATTR(P_SPHERES, true, true); LDS_ATTR(P_SPHERES, false, true);
+#define LDS_ATTR(FEAT, RINGF, MOTIONF, W4F) if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<FEAT, RINGF, MOTIONF, W4F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+        LDS_ATTR(P_SPHERES, true, false, false); LDS_ATTR(P_SPHERES, false, false, false); LDS_ATTR(P_STATIC_SPHERES, true, false, false); LDS_ATTR(P_STATIC_SPHERES, false, false, false);
+        LDS_ATTR(P_SPHERES, true, true, false); LDS_ATTR(P_SPHERES, false, true, false);
+        LDS_ATTR(P_SPHERES, true, false, true); LDS_ATTR(P_SPHERES, false, false, true); LDS_ATTR(P_STATIC_SPHERES, true, false, true); LDS_ATTR(P_STATIC_SPHERES, false, false, true);
 #undef LDS_ATTR
         if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
       }
+      if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: 4-wide tree %s (%u nodes, %u levels, ring of %u, %u B)\n", ds->w4_ok ? "on" : "off", ds->w4_dims.n_nodes, ds->w4_levels,
+                      ds->w4_ring ? ds->w4_ring_cap : 0u, ds->w4_ok ? ldsk_layout(ds->w4_levels, ds->w4_ring ? ds->w4_ring_cap : 0u, ds->w4_dims).total : 0u);
       if (sl) fprintf(stderr, "[rtx] RTX_SCENE_LDS: k_trace_lds %s (ring of %u, %u B of LDS); time-aware boxes %s (ring of %u, %u B)\n", ds->lds_ok ? "on" : "off",
                       ds->lds_ring ? ds->lds_ring_cap : 0u, ldsk_layout(levels, ds->lds_ring ? ds->lds_ring_cap : 0u, ds->lds_dims).total,
                       ds->motion_ok ? "on" : "off", ds->motion_ring ? ds->motion_ring_cap : 0u,
@@ -1078,6 +1116,9 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       ds->leaf_weight = max_count <= 1 ? 1u : 3u;
       // latency-bound wide walks: measured best on the dragon room (639 vs 575 Msamples/s)
       if (ds->nodes4) { ds->leaf_weight = 1u; ds->walk_threshold = 24u; ds->regen_min = 8u; }  // regeneration waits for 8 lanes: 803 -> 824 on C4 (4: 817, 16: 801)
+      // k_trace_lds since the ground is asked first and the node step got shorter (round 3): C2 10 / 12 / 14 / 16 / 18 -> 6153 / 6188 /
+      // 6185 / 6170 / 6140, HEAD Book-1 3859 / 3850 / 3830 / 3808 / 3750 Msamples/s
+      else if (ds->lds_ok) ds->walk_threshold = 12u;
     }
     const char* rm = getenv("RTX_REGEN_MIN");
     if (rm && atoi(rm) >= 1 && atoi(rm) <= 64) ds->regen_min = (uint32_t)atoi(rm);

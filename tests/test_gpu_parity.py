@@ -84,6 +84,11 @@ VARIANTS = [
     {"RTX_TRACE_KERNEL": "persistent"},
     {"RTX_TRACE_KERNEL": "simple"},
     {"RTX_WALK_THRESHOLD": "1", "RTX_LEAF_WEIGHT": "1"},
+    {"RTX_LDS_WIDE": "1"},                  # k_trace_lds on the 4-wide collapse of the tree (measured slower: the A/B partner)
+    {"RTX_LDS_WIDE": "1", "RTX_RING": "0"},
+    {"RTX_MOTION": "0"},                    # HEAD Book-1 on the reference's boxes (unions over the shutter) instead of the time-aware ones
+    {"RTX_MOTION_TOPOLOGY": "0"},           # ... and its tree partitioned by those boxes instead of the mid-interval ones
+    {"RTX_LEAF_FIRST": "0"},                # plain near-child-by-split-axis order everywhere
 ]
 
 
