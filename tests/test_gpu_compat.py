@@ -216,3 +216,47 @@ def test_ppm_image_texture_on_the_device(rtsr, orc, tmp_path):
     a1, r1 = orc.o1_render(b.graph_ptr(), world, cam, cfg, hgt, threads=16)
     assert np.array_equal(screen.accum, a1) and np.array_equal(screen.rgb8, r1)
     assert len(np.unique(screen.rgb8.reshape(-1, 3), axis=0)) > 500  # the picture is on the surfaces
+
+
+def _movers_world(rtsr):
+    """Spheres that move along ALL three axes (Book-1 at HEAD moves along y only), static ones among them, one BVH over (0, 1)."""
+    b = rtsr.Builder(5)
+    mats = [b.lambertian((0.7, 0.3, 0.3)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric(1.5), b.lambertian((0.3, 0.6, 0.8))]
+    objs = [b.sphere((0.0, -300.0, 0.0), 300.0, b.lambertian(b.checker_from_colors((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    for k in range(150):
+        c0 = (8.0 * b.random() - 4.0, 0.25 + 1.5 * b.random(), 8.0 * b.random() - 4.0)
+        r = 0.12 + 0.2 * b.random()
+        if k % 4 == 0:
+            objs.append(b.sphere(c0, r, mats[k % 4]))
+        else:
+            c1 = (c0[0] + 3.0 * b.random() - 1.5, c0[1] + 2.0 * b.random() - 0.5, c0[2] + 3.0 * b.random() - 1.5)
+            objs.append(b.moving_sphere(c0, c1, 0.0, 1.0, r, mats[k % 4]))
+    return b, b.hittable_list([b.bvh_from_list(b.hittable_list(objs), 0.0, 1.0)])
+
+
+@pytest.mark.parametrize("shutter,expect_motion", [((0.0, 1.0), True), ((0.25, 0.6), True), ((0.5, 1.5), False), ((-1.0, 0.5), False)])
+def test_time_aware_boxes_on_the_device(rtsr, orc, monkeypatch, shutter, expect_motion):
+    """k_trace_lds on FlatMotion32 boxes (spheres moving along all axes) against the CPU oracle: bit-identical while the shutter
+    lies inside the BVH's interval; outside it the launcher goes back to the reference's boxes (the lerp is no bound there) -- the
+    frame then still equals the flat-array oracle's, which culls by the same boxes."""
+    b, world = _movers_world(rtsr)
+    cam = rtsr.Camera.new((7.0, 3.0, 8.0), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0), 35.0, 1.5, 0.05, 10.0, shutter[0], shutter[1])
+    cfg = rtsr.Config.new(1.5, 160, 12, 30, 4, seed=9, background=(0.6, 0.7, 0.9))
+    h = rtsr.image_height(cfg)
+    flat = b.flatten(world)
+    assert orc.audit_motion(flat.arrays_ptr(), 32)[0] == 0
+    ref, ref8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    if expect_motion:  # inside the interval the literal object graph agrees too (outside, its own random tree decides what it culls)
+        a1, _ = orc.o1_render(b.graph_ptr(), world, cam, cfg, h, threads=16)
+        assert np.array_equal(a1, ref)
+        walk, c_motion = orc.lds_walk_render(flat.arrays_ptr(), cam, cfg, h, use_motion=True, threads=16)
+        _, c_static = orc.lds_walk_render(flat.arrays_ptr(), cam, cfg, h, use_motion=False, threads=16)
+        assert np.array_equal(walk, ref) and c_motion["node_visits"] < c_static["node_visits"]
+    scene = flat.upload()
+    st = scene.render_device(cam, cfg, want_stats=True)
+    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_lds"
+    screen = scene.render(cam, cfg)
+    assert np.array_equal(screen.accum, ref) and np.array_equal(screen.rgb8, ref8)
+    monkeypatch.setenv("RTX_MOTION", "0")
+    plain = flat.upload().render(cam, cfg)
+    assert np.array_equal(plain.accum, ref)
