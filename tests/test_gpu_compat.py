@@ -237,8 +237,7 @@ def _movers_world(rtsr):
 @pytest.mark.parametrize("shutter,expect_motion", [((0.0, 1.0), True), ((0.25, 0.6), True), ((0.5, 1.5), False), ((-1.0, 0.5), False)])
 def test_time_aware_boxes_on_the_device(rtsr, orc, monkeypatch, shutter, expect_motion):
     """k_trace_lds on FlatMotion32 boxes (spheres moving along all axes) against the CPU oracle: bit-identical while the shutter
-    lies inside the BVH's interval; outside it the launcher goes back to the reference's boxes (the lerp is no bound there) -- the
-    frame then still equals the flat-array oracle's, which culls by the same boxes."""
+    lies inside the BVH's interval; outside it the launcher goes back to the reference's boxes (the lerp is no bound there)."""
     b, world = _movers_world(rtsr)
     cam = rtsr.Camera.new((7.0, 3.0, 8.0), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0), 35.0, 1.5, 0.05, 10.0, shutter[0], shutter[1])
     cfg = rtsr.Config.new(1.5, 160, 12, 30, 4, seed=9, background=(0.6, 0.7, 0.9))
@@ -256,7 +255,14 @@ def test_time_aware_boxes_on_the_device(rtsr, orc, monkeypatch, shutter, expect_
     st = scene.render_device(cam, cfg, want_stats=True)
     assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_lds"
     screen = scene.render(cam, cfg)
-    assert np.array_equal(screen.accum, ref) and np.array_equal(screen.rgb8, ref8)
     monkeypatch.setenv("RTX_MOTION", "0")
     plain = flat.upload().render(cam, cfg)
-    assert np.array_equal(plain.accum, ref)
+    assert np.array_equal(plain.accum, screen.accum) and np.array_equal(plain.rgb8, screen.rgb8)
+    if expect_motion:
+        assert np.array_equal(screen.accum, ref) and np.array_equal(screen.rgb8, ref8)
+    else:
+        # Ray times beyond the interval: a sphere may be OUTSIDE the box the reference gives it (hit.rs:317-327 bounds it by its
+        # boxes at time0 and time1 only), and whether it is still found depends on which boxes a walk happens to enter before
+        # it has a closer hit -- in the reference on its random tree, here on the walker.  No parity claim exists out there;
+        # what is checked is that the launcher fell back to those boxes (same frame as with RTX_MOTION=0, above) and renders.
+        assert np.isfinite(screen.accum).all() and screen.accum.std() > 0.1
