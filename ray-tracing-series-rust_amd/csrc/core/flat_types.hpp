@@ -134,7 +134,7 @@ enum MaterialKind : int32_t {
 struct FlatMaterial {  // 48 B
   int32_t kind;
   int32_t tex;       // albedo / emit texture (Lambertian, DiffuseLight, Isotropic)
-  real albedo[3];  // Metal; for the texture-carrying kinds the colour of `tex` when that is a SolidColor (resolved by the flattener)
+  real albedo[3];  // Metal; for the texture-carrying kinds the colour of `tex` when that is a SolidColor (resolved by the flattener); Dielectric: 1 / ir and the two r0^2 of reflectance (shading.hpp: dielectric_constants)
   real param;      // Metal: fuzz (already clamped to <= 1); Dielectric: ir
   int32_t needs_uv;  // 1 if the texture tree below `tex` contains an Image texture
   int32_t pad;

@@ -151,6 +151,23 @@ RT_HD real reflectance(real cosine, real ref_idx) {
   return r0 + (real(1.0) - r0) * (b * b4);
 }
 
+// reflectance with r0 * r0 already at hand (the flattener's dielectric_constants below computes it with reflectance's own expressions).
+RT_HD real reflectance_r0sq(real cosine, real r0sq) {
+  real b = real(1.0) - cosine;
+  real b2 = b * b;
+  real b4 = b2 * b2;
+  return r0sq + (real(1.0) - r0sq) * (b * b4);
+}
+// What a Dielectric's scatter needs of its index alone: out[0] = 1 / ir (hit.rs:1104-1108), out[1] / out[2] = r0 * r0 of
+// reflectance(cos, 1 / ir) / reflectance(cos, ir) (hit.rs:1095-1097).
+inline void dielectric_constants(real ir, real out[3]) {
+  out[0] = real(1.0) / ir;
+  real r0 = (real(1.0) - out[0]) / (real(1.0) + out[0]);
+  out[1] = r0 * r0;
+  r0 = (real(1.0) - ir) / (real(1.0) + ir);
+  out[2] = r0 * r0;
+}
+
 // Material::emitted (hit.rs:1015-1017 default, 1149-1151 DiffuseLight).
 // Texture::value of a material's texture.  A scene without checker, noise and image textures has SolidColors only, and the
 // flattener has copied each one's colour into the material record: no second, dependent fetch.
@@ -183,28 +200,37 @@ RT_HD bool material_scatter_with_sample(const SceneView& sv, const FlatMaterial&
                                         const HitRecord& rec, Rng& g, Vec3 sphere_sample, Ray* scattered,
                                         Color* attenuation, TraceCounters* cnt) {
   if (COUNT) cnt->scatters++;
+  // Lambertian normalises its sphere sample (random_unit_vector, vec3.rs:297-299), Metal and Dielectric normalise the incoming
+  // direction (hit.rs:1070, 1109): one `v / v.length()` -- a square root and three divisions in f64 -- per material, on different
+  // operands.  Written inside the branches a wave executes it once per material kind present, each time for that kind's lanes
+  // only; hoisted in front of the switch it runs ONCE for all lanes on each lane's own operand.  Same function of the same
+  // operand: the same bits.  (Lanes of kinds that normalise nothing compute a value nobody reads.)
+  const Vec3 unit_in = unit(((F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN) ? sphere_sample : r_in.direction);
   if ((F & F_LAMBERTIAN) && m.kind == MAT_LAMBERTIAN) {  // hit.rs:1039-1051
-    Vec3 scatter_direction = rec.normal + unit(sphere_sample);  // random_unit_vector, vec3.rs:297-299
+    Vec3 scatter_direction = rec.normal + unit_in;  // random_unit_vector, vec3.rs:297-299
     if (near_zero(scatter_direction)) scatter_direction = rec.normal;
     *scattered = make_ray(rec.p, scatter_direction, r_in.time);
     *attenuation = material_texture_value<F, COUNT>(sv, m, rec, cnt);
     return true;
   }
   if ((F & F_METAL) && m.kind == MAT_METAL) {  // hit.rs:1069-1083 (fuzz sphere drawn even when fuzz == 0)
-    Vec3 reflected = reflect(unit(r_in.direction), rec.normal);
+    Vec3 reflected = reflect(unit_in, rec.normal);
     Vec3 dir = reflected + m.param * sphere_sample;
     *scattered = make_ray(rec.p, dir, r_in.time);
     *attenuation = load_v3(m.albedo);
     return dot(dir, rec.normal) > real(0.0);
   }
   if ((F & F_DIELECTRIC) && m.kind == MAT_DIELECTRIC) {  // hit.rs:1103-1126 (uniform drawn only if refraction is possible)
-    real refraction_ratio = rec.front_face ? (real(1.0) / m.param) : m.param;
-    Vec3 unit_direction = unit(r_in.direction);
+    // 1 / ir and reflectance's r0^2 = ((1 - x) / (1 + x))^2 for x = 1 / ir (front face) and x = ir (back face) depend on the
+    // material alone: the flattener evaluates exactly these expressions once (albedo[0..2] of a Dielectric record, flatten.cpp)
+    // instead of two divisions per glass hit -- correctly rounded IEEE divisions on both sides, the same bits.
+    real refraction_ratio = rec.front_face ? m.albedo[0] : m.param;
+    Vec3 unit_direction = unit_in;
     real cos_theta = rt_fmin(dot(-unit_direction, rec.normal), real(1.0));
     real sin_theta = rt_sqrt(real(1.0) - cos_theta * cos_theta);
     bool cannot_refract = refraction_ratio * sin_theta > real(1.0);
     Vec3 direction;
-    if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rng_f64(g))
+    if (cannot_refract || reflectance_r0sq(cos_theta, rec.front_face ? m.albedo[1] : m.albedo[2]) > rng_f64(g))
       direction = reflect(unit_direction, rec.normal);
     else
       direction = refract(unit_direction, rec.normal, refraction_ratio);

@@ -46,6 +46,7 @@ struct WorldDesc;
 struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
   uint32_t n_nodes, n_refs, n_spheres, n_moving;
   uint32_t node_dwords;  // LDSK_NODE_DWORDS, or LDSK_MOTION_NODE_DWORDS for the time-aware instantiation
+  uint32_t n_uni;        // scenes with moving spheres: the last n_uni of n_moving are the scene's STATIC spheres, kept as moving spheres that stand still (n_spheres = 0 then)
 };
 
 // The plain primitive entries beside the BVH in the world list (the dragon room's seven rectangles), as a kernel argument:
@@ -102,17 +103,17 @@ struct DeviceScene {
   // ... and for the 4-wide collapse of the tree (static worlds; RTX_LDS_WIDE=0 turns it off): its node image, ring and stack depth
   bool w4_ok = false, w4_ring = false;
   uint32_t w4_ring_cap = 0, w4_levels = 0;
-  LdsSceneDims w4_dims = {0, 0, 0, 0, 0};
+  LdsSceneDims w4_dims = {0, 0, 0, 0, 0, 0};
   const uint32_t* w4_image = nullptr;
   bool motion_ok = false, motion_ring = false;
   uint32_t motion_ring_cap = 0;
-  LdsSceneDims motion_dims = {0, 0, 0, 0, 0};
+  LdsSceneDims motion_dims = {0, 0, 0, 0, 0, 0};
   double motion_t0 = 0.0, motion_t1 = 0.0;
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
   uint32_t lds_ring_cap = 64;         // entries per wave ring: 64, or 48 / 32 when the scene leaves less LDS
   uint32_t lds_chunk = TRACE_CHUNK_DEFAULT;  // sample indices a wave reserves per grab (RTX_CHUNK)
-  LdsSceneDims lds_dims = {0, 0, 0, 0, 0};
+  LdsSceneDims lds_dims = {0, 0, 0, 0, 0, 0};
   bool force_wq = false;              // RTX_TRACE_KERNEL=wq: workgroup-queue kernel (trace_wq.inc)
   bool wq_diag = false;               // RTX_TRACE_KERNEL=wq_diag: stage occupancy counters on stderr (never timed)
   bool wq_ok = false;                 // world fits k_trace_wq's 16-bit work items and LDS budget
@@ -989,7 +990,12 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       int lds_max = 0;
       (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
       if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size(), LDSK_NODE_DWORDS};
+      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size(), LDSK_NODE_DWORDS, 0u};
+      if (fs.features & rt::F_MOVING_SPHERE) {  // k_trace_lds<P_SPHERES>: one kind of primitive in LDS (trace_lds.inc: UNI)
+        ds->lds_dims.n_uni = (uint32_t)fs.spheres.size();
+        ds->lds_dims.n_moving += ds->lds_dims.n_uni;
+        ds->lds_dims.n_spheres = 0u;
+      }
       ds->motion_dims = ds->lds_dims;
       ds->motion_dims.node_dwords = LDSK_MOTION_NODE_DWORDS;
       const uint32_t levels = (uint32_t)fs.max_stack + 1u;

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include "../core/geometry.hpp"
+#include "../core/shading.hpp"
 #include "flat_scene.hpp"
 
 namespace rtx {
@@ -402,6 +403,7 @@ struct Flattener {
         const GTexture& t = g.textures[m.tex];
         f.albedo[0] = t.color[0]; f.albedo[1] = t.color[1]; f.albedo[2] = t.color[2];
       }
+      if (m.kind == rt::MAT_DIELECTRIC) rt::dielectric_constants(f.param, f.albedo);  // 1 / ir and the two r0^2 (core/shading.hpp)
       out.materials.push_back(f);
     }
     out.perlins = g.perlins;
