@@ -109,6 +109,8 @@ struct DeviceScene {
   uint32_t motion_ring_cap = 0;
   LdsSceneDims motion_dims = {0, 0, 0, 0, 0, 0};
   double motion_t0 = 0.0, motion_t1 = 0.0;
+  bool mv_common = false;             // every MovingSphere of the scene has the same (time0, time1) = (mv_t0, mv_t1): k_trace_lds divides once per bounce (RTX_MV_COMMON=0: off)
+  double mv_t0 = 0.0, mv_t1 = 1.0;
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
   bool lds_ring = false;
   uint32_t lds_ring_cap = 64;         // entries per wave ring: 64, or 48 / 32 when the scene leaves less LDS
@@ -514,7 +516,8 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
 #define LAUNCH_LDS2(FEAT, RINGF, MOTIONF, W4F)                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF, MOTIONF, W4F>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, lds_levels, dims, m_t0, m_inv, ds->w4_image)
+                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, lds_levels, dims, m_t0, m_inv, ds->w4_image, \
+                     ds->mv_common ? 1u : 0u, (rt::real)ds->mv_t0, (rt::real)ds->mv_t1)
 #define LAUNCH_LDS(FEAT, MOTIONF, W4F) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF, W4F); } else { LAUNCH_LDS2(FEAT, false, MOTIONF, W4F); } } while (0)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
         if ((feat & ~P_STATIC_SPHERES) == 0) { if (w4) { LAUNCH_LDS(P_STATIC_SPHERES, false, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false, false); } }
@@ -991,6 +994,13 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
       if (lds_max > 160 * 1024) lds_max = 160 * 1024;
       ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size(), LDSK_NODE_DWORDS, 0u};
+      if (!fs.moving_spheres.empty()) {
+        const char* mc = getenv("RTX_MV_COMMON");
+        bool same = !(mc && atoi(mc) == 0);
+        for (const rt::FlatMovingSphere& ms : fs.moving_spheres)
+          same = same && ms.time0 == fs.moving_spheres[0].time0 && ms.time1 == fs.moving_spheres[0].time1;
+        if (same) { ds->mv_common = true; ds->mv_t0 = (double)fs.moving_spheres[0].time0; ds->mv_t1 = (double)fs.moving_spheres[0].time1; }
+      }
       if (fs.features & rt::F_MOVING_SPHERE) {  // k_trace_lds<P_SPHERES>: one kind of primitive in LDS (trace_lds.inc: UNI)
         ds->lds_dims.n_uni = (uint32_t)fs.spheres.size();
         ds->lds_dims.n_moving += ds->lds_dims.n_uni;
