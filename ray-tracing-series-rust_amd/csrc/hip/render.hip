@@ -109,6 +109,11 @@ struct DeviceScene {
   uint32_t motion_ring_cap = 0;
   LdsSceneDims motion_dims = {0, 0, 0, 0, 0, 0};
   double motion_t0 = 0.0, motion_t1 = 0.0;
+  // Passes of one render pipelined two deep (render_impl): odd passes run on an internal stream with their own half of the sample
+  // buffer and their own work counter, so the tail, the reduction of pass k and the start of pass k + 1 overlap.  RTX_PASS_PIPELINE=0: off.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_pass[3] = {nullptr, nullptr, nullptr};  // reduction of an even / odd pass done; start of the render
+  bool pass_pipeline = true;
   bool mv_common = false;             // every MovingSphere of the scene has the same (time0, time1) = (mv_t0, mv_t1): k_trace_lds divides once per bounce (RTX_MV_COMMON=0: off)
   double mv_t0 = 0.0, mv_t1 = 1.0;
   bool lds_ok = false;                // scene geometry fits in LDS -> k_trace_lds (RTX_SCENE_LDS=0 turns it off)
@@ -184,6 +189,9 @@ static void free_device_scene(DeviceScene* ds) {
   if (ds->wave_host_ctrl) (void)hipHostFree(ds->wave_host_ctrl);
   for (int i = 0; i < 2; ++i)
     if (ds->ev[i]) (void)hipEventDestroy(ds->ev[i]);
+  for (int i = 0; i < 3; ++i)
+    if (ds->ev_pass[i]) (void)hipEventDestroy(ds->ev_pass[i]);
+  if (ds->aux_stream) (void)hipStreamDestroy(ds->aux_stream);
   delete ds;
 }
 
@@ -422,14 +430,21 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   uint64_t per_sample_plane = npix * 24ull;
   uint32_t spp = (uint32_t)cfg->samples_per_pixel;
   uint32_t spp_pass = spp;
-  if (per_sample_plane > 0 && (uint64_t)spp * per_sample_plane > budget) {
-    spp_pass = (uint32_t)(budget / per_sample_plane);
+  // Two passes in flight (below) when the render needs several passes anyway (C5: 16, C3: 10): each pass then gets half of the
+  // buffer.  A render that fits one pass stays one launch -- cut in two it gains the overlapped half of its reduction and loses as
+  // much to the second launch (C2: 6550 against 6574 Msamples/s; with two FRAMES in flight on top, 6644 against 6722), whereas
+  // C5 gains 1.7 %.  Not for the counting / timing entry points (stats != NULL synchronises per pass).
+  const bool pipeline = ds->pass_pipeline && !COUNT && stats == nullptr && !ds->force_simple && per_sample_plane > 0 &&
+                        (uint64_t)spp * per_sample_plane > budget && budget / 2 >= per_sample_plane;
+  const uint64_t pass_budget = pipeline ? budget / 2 : budget;
+  if (per_sample_plane > 0 && (uint64_t)spp_pass * per_sample_plane > pass_budget) {
+    spp_pass = (uint32_t)(pass_budget / per_sample_plane);
     if (spp_pass < 1) spp_pass = 1;
   }
   // a pass's (sample, pixel) index space is addressed with 32-bit indices
   while (spp_pass > 1 && (uint64_t)spp_pass * npix >= 0xFFFF0000ull) --spp_pass;
   if ((uint64_t)spp_pass * npix >= 0xFFFF0000ull) { set_error("render: shard too large for one pass"); return RTX_EINVAL; }
-  size_t need_samples = (size_t)spp_pass * per_sample_plane;
+  size_t need_samples = (size_t)spp_pass * per_sample_plane * (pipeline ? 2 : 1);
   if (need_samples > ds->samples_bytes) {
     if (ds->samples) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(ds->samples)); ds->samples = nullptr; ds->samples_bytes = 0; }
     // out of memory: halve the pass until the buffer fits (down to one sample per pass) before giving up
@@ -443,7 +458,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         return me == hipErrorOutOfMemory ? RTX_ENOMEM : RTX_EHIP;
       }
       spp_pass = (spp_pass + 1) / 2;
-      need_samples = (size_t)spp_pass * per_sample_plane;
+      need_samples = (size_t)spp_pass * per_sample_plane * (pipeline ? 2 : 1);
     }
     ds->samples_bytes = need_samples;
   }
@@ -458,7 +473,11 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
     accum = ds->accum;
   }
   if (!ds->counters) HIP_TRY(hipMalloc((void**)&ds->counters, sizeof(rt::TraceCounters)));
-  if (!ds->work_counter) HIP_TRY(hipMalloc((void**)&ds->work_counter, sizeof(unsigned int)));
+  if (!ds->work_counter) HIP_TRY(hipMalloc((void**)&ds->work_counter, 2 * sizeof(unsigned int)));
+  if (pipeline && !ds->aux_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&ds->aux_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventCreateWithFlags(&ds->ev_pass[i], hipEventDisableTiming));
+  }
   if (!ds->ev[0]) { HIP_TRY(hipEventCreate(&ds->ev[0])); HIP_TRY(hipEventCreate(&ds->ev[1])); }
   if (COUNT) HIP_TRY(hipMemsetAsync(ds->counters, 0, sizeof(rt::TraceCounters), stream));
 
@@ -480,7 +499,27 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
   int passes = 0;
   int32_t kernel_used = RTX_KERNEL_SIMPLE;
   if (npix > 0) {
+    // Passes two deep: even passes on the caller's stream, odd ones on ds->aux_stream, each with its own half of the sample
+    // buffer and its own work counter.  Within a stream: trace(k), reduce(k), trace(k + 2), ... -- so a half is not overwritten
+    // before it has been summed; across streams reduce(k) waits for reduce(k - 1) -- so every pixel's samples are still added in
+    // ascending order, bit for bit what one stream does.  What overlaps: the last waves of trace(k) (a few long paths in
+    // otherwise idle CUs), reduce(k) and the first waves of trace(k + 1).
+    double* const samples_base = ds->samples;
+    unsigned int* const counter_base = ds->work_counter;
+    struct RestoreScene {
+      DeviceScene* d; double* s; unsigned int* w;
+      ~RestoreScene() { d->samples = s; d->work_counter = w; }
+    } restore_scene{ds, samples_base, counter_base};
+    hipStream_t const caller_stream = stream;
+    if (pipeline) {
+      HIP_TRY(hipEventRecord(ds->ev_pass[2], caller_stream));
+      HIP_TRY(hipStreamWaitEvent(ds->aux_stream, ds->ev_pass[2], 0));
+    }
     for (uint32_t s_begin = 0; s_begin < spp; s_begin += spp_pass, ++passes) {
+      const int half = pipeline ? (passes & 1) : 0;
+      hipStream_t stream = half ? ds->aux_stream : caller_stream;  // (shadows the parameter: every launch below goes to this pass's stream)
+      ds->samples = samples_base + (size_t)half * (size_t)spp_pass * (size_t)npix * 3u;
+      ds->work_counter = counter_base + half;
       uint32_t s_count = spp - s_begin < spp_pass ? spp - s_begin : spp_pass;
       uint32_t total = (uint32_t)((uint64_t)s_count * npix);
       if (stats) HIP_TRY(hipEventRecord(ds->ev[0], stream));
@@ -730,10 +769,13 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
         trace_ms += ms;
       }
       uint32_t pgrid = (uint32_t)((npix + 255) / 256);
+      if (pipeline && passes > 0) HIP_TRY(hipStreamWaitEvent(stream, ds->ev_pass[1 - half], 0));  // the previous pass's sums are in
       hipLaunchKernelGGL(k_reduce_samples, dim3(pgrid), dim3(256), 0, stream, ds->samples, accum,
                          (uint32_t)npix, s_count, s_begin == 0 ? 1 : 0);
       HIP_TRY(hipGetLastError());
+      if (pipeline) HIP_TRY(hipEventRecord(ds->ev_pass[half], stream));
     }
+    if (pipeline && passes > 0 && ((passes - 1) & 1)) HIP_TRY(hipStreamWaitEvent(caller_stream, ds->ev_pass[1], 0));
     if (d_rgb8_out) {
       uint32_t pgrid = (uint32_t)((npix + 255) / 256);
       hipLaunchKernelGGL(k_tonemap, dim3(pgrid), dim3(256), 0, stream, accum, d_rgb8_out, (uint32_t)npix, spp);
@@ -1140,6 +1182,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
     if (rm && atoi(rm) >= 1 && atoi(rm) <= 64) ds->regen_min = (uint32_t)atoi(rm);
     const char* lw = getenv("RTX_LEAF_WEIGHT");
     if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
+    const char* pp = getenv("RTX_PASS_PIPELINE");
+    if (pp) ds->pass_pipeline = atoi(pp) != 0;
     const char* wt = getenv("RTX_WALK_THRESHOLD");
     if (wt && atoi(wt) >= 1 && atoi(wt) <= 64) ds->walk_threshold = (uint32_t)atoi(wt);
   }
