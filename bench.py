@@ -5,24 +5,28 @@
 
 A "step" is one full render of the workload: trace kernel(s) + ordered sample reduction + tone map,
 scene already resident in HBM.  Steps are pipelined two deep (two resident copies of the scene, two streams), so that
-the tail of one frame overlaps the start of the next; the timed region covers K whole frames from first launch to last byte.  At N=1 the workload is BASELINE.json configs[1] ("c2": Book-1 final
+the tail of one frame overlaps the start of the next; the timed region covers K whole frames from first launch to last byte
+(`single_frame` in the line = one frame at a time, what ONE rtx_render_device call delivers).  At N=1 the workload is BASELINE.json configs[1] ("c2": Book-1 final
 scene, 800x533, 500 spp, depth 50).  For N>1 the SAME image is sharded by rows over the ranks (one
 process per GPU, launched by torch.distributed.run) and the tone-mapped shards are gathered to rank 0
-with one RCCL gather per step: total work is fixed, so scaling is "strong".
+with one RCCL gather per step: total work is fixed, so scaling is "strong"; the line then also carries `c5` (one frame of
+BASELINE's scaling config at a reduced, stated spp, with per-rank render and gather times) and `ranks_reported`.
+`--single-process` measures the C ABI's one-process path (rtx_multi_*) instead; `--same-device` rehearses on one GPU.
 
 One JSON line is printed by rank 0.  Besides the driver's contract it carries
 
   roofline      bound = "valu": the trace kernels are bound by vector-ALU ISSUE (the Book-1 scene lives in LDS; HBM
                 sees 2 % of its peak).  Everything in it is measured in THIS run (rank 0, N = 1) by rocprofv3 --pmc
                 passes over a child process that renders the same workload:
-                  frac = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel clocks)
-                = clocks in which a SIMD's VALU is occupied by an instruction / clocks available, kernel clocks =
-                GRBM_GUI_ACTIVE / 8 XCDs of the same pass.  (ACTIVE_INST_VALU alone double counts quad-cycles that two
-                2-clock instructions share -- it exceeded the available time in round 1; VALU2 is exactly that overlap,
-                see PMC_PASSES.)  `useful` = frac x lane utilisation.  As a cross-check the same fraction is priced
-                from per-class instruction counts (SQ_INSTS_VALU_*) x per-opcode issue costs measured by lib/issue_calib
-                in this run (tools/gen_issue_calib.py).  HBM (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and the
-                SURVEY 8(d) algorithmic-bytes figure ride along as secondary fields.
+                  busy  = 4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x kernel clocks)
+                        = clocks in which a SIMD's VALU is occupied by an instruction / clocks available (kernel clocks =
+                          GRBM_GUI_ACTIVE / 8 XCDs of the same pass; ACTIVE_INST_VALU alone double counts quad-cycles that
+                          two 2-clock instructions share -- VALU2 is exactly that overlap, see PMC_PASSES)
+                  lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+                  frac  = useful = busy x lanes          `achieved` = the matching rate of useful issue clocks
+                `lane_clocks_per_sample` = busy clocks x 64 x lanes / samples: the work-based figure that falls when the
+                algorithm improves.  HBM (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and the SURVEY 8(d)
+                algorithmic-bytes figure ride along as secondary fields.
   cpu_baseline  the CPU oracle O1 (literal restatement of the reference's path, "port") timed on this
                 box's host cores on a bounded sample of the same workload
   other_workloads  (N = 1) the other BASELINE configs on the HIP path, a few steps each: Book-1 as HEAD builds it,
