@@ -16,7 +16,8 @@ import sys
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG_DIR, "lib", "librtx_hip.so")
+# RTX_LIBRARY: another build of the same library (scripts/ab_builds.sh: two builds timed in one session on one GPU)
+_LIB_PATH = os.environ.get("RTX_LIBRARY") or os.path.join(_PKG_DIR, "lib", "librtx_hip.so")
 
 RTX_OK, RTX_EINVAL, RTX_ENOMEM, RTX_EHIP, RTX_EUNSUPPORTED, RTX_EIO, RTX_ENCCL = 0, 1, 2, 3, 4, 5, 6
 _STATUS_NAMES = {0: "RTX_OK", 1: "RTX_EINVAL", 2: "RTX_ENOMEM", 3: "RTX_EHIP", 4: "RTX_EUNSUPPORTED", 5: "RTX_EIO", 6: "RTX_ENCCL"}

@@ -58,7 +58,8 @@ def licm_flags():
 
 
 def flags_for(src):
-    return HIP_FLAGS + (licm_flags() if src in TRACE_SOURCES else [])
+    # RTX_EXTRA_HIPFLAGS: extra -D switches for an experiment build (scripts/ab_builds.sh); never set for the product
+    return HIP_FLAGS + (licm_flags() if src in TRACE_SOURCES else []) + os.environ.get("RTX_EXTRA_HIPFLAGS", "").split()
 
 
 def _hipcc():
