@@ -97,6 +97,7 @@ struct DeviceScene {
   int stream_blocks_per_cu[2] = {1, 1};
   uint32_t walk_threshold = 18;       // RTX_WALK_THRESHOLD (1 = never carry a walk over); 18 measured best on C2 (12..22 within 1 %)
   uint32_t regen_min = 1;             // wide k_trace_vote: lanes that must be waiting before the wave regenerates (RTX_REGEN_MIN)
+  bool single_leaf = false;           // every BVH leaf holds one primitive (k_trace_lds tests it without a loop)
   uint32_t leaf_weight = 3;           // RTX_LEAF_WEIGHT: node lanes x weight >= leaf lanes -> node step (default: leaf size + 1... see upload)
   // the same plan for the time-aware instantiation (bigger node records: its own ring size); chosen per render, when the camera's
   // shutter lies inside the BVH's time interval [motion_t0, motion_t1] (RTX_MOTION=0 turns it off)
@@ -555,7 +556,7 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
 #define LAUNCH_LDS2(FEAT, RINGF, MOTIONF, W4F)                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_lds<FEAT, RINGF, MOTIONF, W4F>), dim3(grid), dim3(LDSK_BLOCK), L.total, stream, \
                      ds->view, rp, sm, s_begin, total, (uint32_t)npix, ds->samples, ds->work_counter,      \
-                     ds->leaf_weight, ds->walk_threshold, ds->lds_chunk, ring_cap, lds_levels, dims, m_t0, m_inv, ds->w4_image, \
+                     ds->leaf_weight, ds->walk_threshold | (ds->single_leaf ? 0x100u : 0u), ds->lds_chunk, ring_cap, lds_levels, dims, m_t0, m_inv, ds->w4_image, \
                      ds->mv_common ? 1u : 0u, (rt::real)ds->mv_t0, (rt::real)ds->mv_t1)
 #define LAUNCH_LDS(FEAT, MOTIONF, W4F) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF, W4F); } else { LAUNCH_LDS2(FEAT, false, MOTIONF, W4F); } } while (0)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
@@ -1172,6 +1173,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         for (int ch = 0; ch < 2; ++ch)
           if (nd.child[ch] < 0) max_count = std::max(max_count, rt::leaf_count(nd.child[ch]));
       ds->leaf_weight = max_count <= 1 ? 1u : 3u;
+      ds->single_leaf = max_count <= 1;
       // latency-bound wide walks: measured best on the dragon room (639 vs 575 Msamples/s)
       if (ds->nodes4) { ds->leaf_weight = 1u; ds->walk_threshold = 24u; ds->regen_min = 8u; }  // regeneration waits for 8 lanes: 803 -> 824 on C4 (4: 817, 16: 801)
       // k_trace_lds since the ground is asked first and the node step got shorter (round 3): C2 10 / 12 / 14 / 16 / 18 -> 6153 / 6188 /
@@ -1184,6 +1186,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
     if (lw && atoi(lw) >= 1 && atoi(lw) <= 64) ds->leaf_weight = (uint32_t)atoi(lw);
     const char* pp = getenv("RTX_PASS_PIPELINE");
     if (pp) ds->pass_pipeline = atoi(pp) != 0;
+    const char* sg = getenv("RTX_SINGLE_LEAF");
+    if (sg && atoi(sg) == 0) ds->single_leaf = false;  // A/B: the general leaf loop on a tree of one-primitive leaves
     const char* wt = getenv("RTX_WALK_THRESHOLD");
     if (wt && atoi(wt) >= 1 && atoi(wt) <= 64) ds->walk_threshold = (uint32_t)atoi(wt);
   }
