@@ -224,10 +224,27 @@ __device__ __forceinline__ void shard_pixel(const ShardMap& m, uint32_t lp, uint
 struct LdsStack {
   int32_t* base;
   int n;
+  static constexpr bool kBottom = false;
   __device__ __forceinline__ void reset() { n = 0; }
   __device__ __forceinline__ void push(int32_t v) { base[n * TRACE_BLOCK] = v; ++n; }
   __device__ __forceinline__ int32_t pop() { --n; return base[n * TRACE_BLOCK]; }
   __device__ __forceinline__ bool empty() const { return n == 0; }
+};
+// The same stack with a bottom: slot 0 of every thread holds "walk done" (0x7fffffff = WALK_DONE, trace_vote.inc) while a walk
+// is on and the walk's own entries start at slot 1, so popping an "empty" stack returns "done" like any other item -- no
+// emptiness test, no branch in the step functions (k_trace_vote, k_trace_world; k_trace_lds has its 16-bit twin).  The spare
+// level every launcher already sizes the stacks with (tree height + 1, wide: peak + 1) is this slot.  reset() writes it anew
+// for every walk: the wide step's last act on an exhausted stack is to dump its four missed children there (walk_node_step4).
+struct LdsStackB {
+  int32_t* base;
+  int n;
+  static constexpr bool kBottom = true;
+  __device__ __forceinline__ void reset() { base[0] = 0x7fffffff; n = 1; }
+  __device__ __forceinline__ void init() { reset(); }
+  __device__ __forceinline__ void push(int32_t v) { base[n * TRACE_BLOCK] = v; ++n; }
+  __device__ __forceinline__ int32_t pop() { --n; return base[n * TRACE_BLOCK]; }
+  __device__ __forceinline__ int32_t top() const { return base[(n - 1) * TRACE_BLOCK]; }
+  __device__ __forceinline__ bool empty() const { return n <= 1; }
 };
 
 __device__ __forceinline__ void flush_counters(const rt::TraceCounters& c, rt::TraceCounters* g) {
@@ -941,7 +958,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         int peak = 0;
         for (const rt::FlatEntry& e : fs.entries)
           if (e.kind == rt::ENTRY_BVH) peak = std::max(peak, build_wide_nodes(fs.nodes, e.a, &wide));
-        ds->wide_levels = peak + 1;
+        ds->wide_levels = peak + 1;  // (the spare level is the bottom slot of LdsStackB; walk_node_step4 needs none of its own)
         const size_t wide_lds = (size_t)ds->wide_levels * TRACE_BLOCK * sizeof(int32_t);
         int nbw = 0;
         bool ok = wide_lds <= 64 * 1024;
