@@ -1053,7 +1053,8 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       int lds_max = 0;
       (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, ds->device);
       if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, (uint32_t)fs.spheres.size(), (uint32_t)fs.moving_spheres.size(), LDSK_NODE_DWORDS, 0u};
+      // primitive records in LDS: one per leaf slot, in slot order (trace_lds.inc) -- spheres, or moving spheres when the scene has any
+      ds->lds_dims = {(uint32_t)fs.nodes32.size(), max_end, max_end, 0u, LDSK_NODE_DWORDS, 0u};
       if (!fs.moving_spheres.empty()) {
         const char* mc = getenv("RTX_MV_COMMON");
         bool same = !(mc && atoi(mc) == 0);
@@ -1063,7 +1064,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       }
       if (fs.features & rt::F_MOVING_SPHERE) {  // k_trace_lds<P_SPHERES>: one kind of primitive in LDS (trace_lds.inc: UNI)
         ds->lds_dims.n_uni = (uint32_t)fs.spheres.size();
-        ds->lds_dims.n_moving += ds->lds_dims.n_uni;
+        ds->lds_dims.n_moving = max_end;
         ds->lds_dims.n_spheres = 0u;
       }
       ds->motion_dims = ds->lds_dims;
