@@ -107,6 +107,26 @@ def test_kernel_variants_equal_oracle(rtsr, orc, monkeypatch, env, sid, width, a
     assert np.array_equal(screen.rgb8, ref_rgb8)
 
 
+@pytest.mark.parametrize("sid", [100, 13])
+@pytest.mark.parametrize("max_leaf", [2, 4])
+def test_scene_in_lds_with_leaves_of_several_primitives(rtsr, orc, sid, max_leaf):
+    """k_trace_lds keeps its sphere records in LDS in leaf-slot order and has a straight-line path for trees of one-primitive
+    leaves (the default for spheres); here the same scenes with leaves of up to 2 / 4 spheres: the general leaf loop, slots
+    f .. f + k - 1 of one leaf, static and moving spheres mixed in one leaf at HEAD."""
+    b = rtsr.Builder(1)
+    world, cam, bg = b.get_world_cam(sid)
+    cfg = rtsr.Config.new(1.5, 132, 6, 50, 10, seed=21, background=bg)
+    flat = b.flatten(world, max_leaf=max_leaf)
+    h = rtsr.image_height(cfg)
+    scene = flat.upload()
+    st = scene.render_device(cam, cfg, want_stats=True)
+    assert rtsr.trace_kernel_name(st.trace_kernel) == "k_trace_lds"
+    screen = scene.render(cam, cfg)
+    ref_accum, ref_rgb8 = orc.o2_render(flat.arrays_ptr(), cam, cfg, h, threads=16)
+    assert np.array_equal(screen.accum, ref_accum)
+    assert np.array_equal(screen.rgb8, ref_rgb8)
+
+
 @pytest.mark.parametrize("scene_seed", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("sid", [100, 13])
 def test_other_scene_seeds(rtsr, orc, scene_seed, sid):
