@@ -70,7 +70,7 @@ RT_HD real perlin_noise(const FlatPerlin& pn, Point3 p, TraceCounters* cnt) {
     for (uint32_t dj = 0; dj < 2; ++dj)
       RT_NO_UNROLL
       for (uint32_t dk = 0; dk < 2; ++dk) {
-        int32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
+        int32_t h = (int32_t)xor3((uint32_t)pn.perm_x[(i + di) & 255u], (uint32_t)pn.perm_y[(j + dj) & 255u], (uint32_t)pn.perm_z[(k + dk) & 255u]);
         Vec3 c = load_v3(pn.ranvec[h]);
         real i1 = (real)di, j1 = (real)dj, k1 = (real)dk;
         Vec3 weight_v = v3(u - i1, v - j1, w - k1);
