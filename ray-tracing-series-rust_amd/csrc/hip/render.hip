@@ -44,9 +44,9 @@ typedef const FlatNode4 FlatNode4Dev;
 struct WorldDesc;
 
 struct LdsSceneDims {  // what k_trace_lds (trace_lds.inc) copies into LDS
-  uint32_t n_nodes, n_refs, n_spheres, n_moving;
+  uint32_t n_nodes, n_refs, n_spheres, n_moving;  // n_refs = leaf slots; one record per slot, in slot order: n_spheres or n_moving = n_refs
   uint32_t node_dwords;  // LDSK_NODE_DWORDS, or LDSK_MOTION_NODE_DWORDS for the time-aware instantiation
-  uint32_t n_uni;        // scenes with moving spheres: the last n_uni of n_moving are the scene's STATIC spheres, kept as moving spheres that stand still (n_spheres = 0 then)
+  uint32_t n_uni;        // scenes with moving spheres: how many of the n_moving records are the scene's STATIC spheres, kept as moving spheres that stand still (n_spheres = 0 then; informational: the kernel decides per slot)
 };
 
 // The plain primitive entries beside the BVH in the world list (the dragon room's seven rectangles), as a kernel argument:
