@@ -109,6 +109,7 @@ struct DeviceScene {
   bool motion_ok = false, motion_ring = false;
   uint32_t motion_ring_cap = 0;
   LdsSceneDims motion_dims = {0, 0, 0, 0, 0, 0};
+  int motion_axis = -1;               // 0 / 1 / 2: every slope of the time-aware boxes is zero except along this axis (-1: no such axis)
   double motion_t0 = 0.0, motion_t1 = 0.0;
   // Passes of one render pipelined two deep (render_impl): odd passes run on an internal stream with their own half of the sample
   // buffer and their own work counter, so the tail, the reduction of pass k and the start of pass k + 1 overlap.  RTX_PASS_PIPELINE=0: off.
@@ -577,10 +578,11 @@ static rtx_status render_impl(DeviceScene* ds, const RtxCamera* cam, const RtxCo
                      ds->mv_common ? 1u : 0u, (rt::real)ds->mv_t0, (rt::real)ds->mv_t1)
 #define LAUNCH_LDS(FEAT, MOTIONF, W4F) do { if (ring) { LAUNCH_LDS2(FEAT, true, MOTIONF, W4F); } else { LAUNCH_LDS2(FEAT, false, MOTIONF, W4F); } } while (0)
         // static spheres without checker textures (the Book-1 final scene): the leaner instantiation
-        if ((feat & ~P_STATIC_SPHERES) == 0) { if (w4) { LAUNCH_LDS(P_STATIC_SPHERES, false, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, false, false); } }
-        else if (motion) { LAUNCH_LDS(P_SPHERES, true, false); }
-        else if (w4) { LAUNCH_LDS(P_SPHERES, false, true); }
-        else { LAUNCH_LDS(P_SPHERES, false, false); }
+        if ((feat & ~P_STATIC_SPHERES) == 0) { if (w4) { LAUNCH_LDS(P_STATIC_SPHERES, 0u, true); } else { LAUNCH_LDS(P_STATIC_SPHERES, 0u, false); } }
+        else if (motion && ds->motion_axis == 1) { LAUNCH_LDS(P_SPHERES, 3u, false); }  // slopes along y only (Book-1 at HEAD)
+        else if (motion) { LAUNCH_LDS(P_SPHERES, 1u, false); }
+        else if (w4) { LAUNCH_LDS(P_SPHERES, 0u, true); }
+        else { LAUNCH_LDS(P_SPHERES, 0u, false); }
 #undef LAUNCH_LDS
 #undef LAUNCH_LDS2
 #ifdef RTX_EXPERIMENTAL_KERNELS
@@ -1069,6 +1071,18 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       }
       ds->motion_dims = ds->lds_dims;
       ds->motion_dims.node_dwords = LDSK_MOTION_NODE_DWORDS;
+      {
+        // slopes along one axis only?  (a scene whose spheres all move the same way; the y-only instantiation exists: Book-1 at HEAD)
+        bool moves[3] = {false, false, false};
+        for (const rt::FlatMotion32& m : fs.motion32)
+          for (int ch = 0; ch < 2; ++ch)
+            for (int a = 0; a < 3; ++a) moves[a] = moves[a] || m.dlo[ch][a] != 0.0f || m.dhi[ch][a] != 0.0f;
+        const char* ma = getenv("RTX_MOTION_AXIS");
+        if (!fs.motion32.empty() && moves[1] && !moves[0] && !moves[2] && !(ma && atoi(ma) == 0)) {
+          ds->motion_axis = 1;
+          ds->motion_dims.node_dwords = LDSK_MOTION1_NODE_DWORDS;
+        }
+      }
       const uint32_t levels = (uint32_t)fs.max_stack + 1u;
       const char* ck = getenv("RTX_CHUNK");
       if (ck && atoi(ck) >= 64 && atoi(ck) <= 65536) ds->lds_chunk = (uint32_t)atoi(ck);
@@ -1076,7 +1090,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
       const char* rg = getenv("RTX_RING");
       const bool want_ring = !(rg && atoi(rg) == 0);
       if (max_count <= 4 && max_end <= LDSK_MAX_SLOTS && !(sl && atoi(sl) == 0) && lds_max > 0) {
-        for (uint32_t cap : {64u, 48u, 32u}) {
+        for (uint32_t cap : {64u, 48u}) {
           if (want_ring && !ds->lds_ok && ldsk_layout(levels, cap, ds->lds_dims).total <= (uint32_t)lds_max) {
             ds->lds_ok = true; ds->lds_ring = true; ds->lds_ring_cap = cap;
           }
@@ -1097,7 +1111,7 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
             ds->w4_dims.n_nodes = n_wide;
             ds->w4_dims.node_dwords = LDSK_WIDE_NODE_DWORDS;
             ds->w4_levels = wl;
-            for (uint32_t cap : {64u, 48u, 32u}) {
+            for (uint32_t cap : {64u, 48u}) {
               if (want_ring && !ds->w4_ok && ldsk_layout(wl, cap, ds->w4_dims).total <= (uint32_t)lds_max) {
                 ds->w4_ok = true; ds->w4_ring = true; ds->w4_ring_cap = cap;
               }
@@ -1114,9 +1128,9 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         const char* mo = getenv("RTX_MOTION");
         if (ds->lds_ok && !fs.motion32.empty() && (fs.features & rt::F_MOVING_SPHERE) && (double)be.f[0] < (double)be.f[1] && !(mo && atoi(mo) == 0)) {
           ds->motion_t0 = (double)be.f[0]; ds->motion_t1 = (double)be.f[1];
-          // (a ring of fewer than 32 rays is worse than none: its refills run with that few lanes -- HEAD Book-1, ring of 16: 3137
-          // Msamples/s, no ring: 3774)
-          for (uint32_t cap : {64u, 48u, 32u}) {
+          // (a small ring is worse than none: its refills run with that few lanes -- HEAD Book-1, ring of 16: 3137 Msamples/s against
+          // 3774 without; ring of 32 on the final build of round 3: 4963 against 5196.  Rings are 64 or 48 entries, or absent.)
+          for (uint32_t cap : {64u, 48u}) {
             if (want_ring && !ds->motion_ok && ldsk_layout(levels, cap, ds->motion_dims).total <= (uint32_t)lds_max) {
               ds->motion_ok = true; ds->motion_ring = true; ds->motion_ring_cap = cap;
             }
@@ -1130,9 +1144,9 @@ static rtx_status scene_upload_impl(const FlatScene& fs, DeviceScene** out) {
         const int bytes = lds_max;
         hipError_t ae = hipSuccess;
 #define LDS_ATTR(FEAT, RINGF, MOTIONF, W4F) if (ae == hipSuccess) ae = hipFuncSetAttribute((const void*)k_trace_lds<FEAT, RINGF, MOTIONF, W4F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-        LDS_ATTR(P_SPHERES, true, false, false); LDS_ATTR(P_SPHERES, false, false, false); LDS_ATTR(P_STATIC_SPHERES, true, false, false); LDS_ATTR(P_STATIC_SPHERES, false, false, false);
-        LDS_ATTR(P_SPHERES, true, true, false); LDS_ATTR(P_SPHERES, false, true, false);
-        LDS_ATTR(P_SPHERES, true, false, true); LDS_ATTR(P_SPHERES, false, false, true); LDS_ATTR(P_STATIC_SPHERES, true, false, true); LDS_ATTR(P_STATIC_SPHERES, false, false, true);
+        LDS_ATTR(P_SPHERES, true, 0u, false); LDS_ATTR(P_SPHERES, false, 0u, false); LDS_ATTR(P_STATIC_SPHERES, true, 0u, false); LDS_ATTR(P_STATIC_SPHERES, false, 0u, false);
+        LDS_ATTR(P_SPHERES, true, 1u, false); LDS_ATTR(P_SPHERES, false, 1u, false); LDS_ATTR(P_SPHERES, true, 3u, false); LDS_ATTR(P_SPHERES, false, 3u, false);
+        LDS_ATTR(P_SPHERES, true, 0u, true); LDS_ATTR(P_SPHERES, false, 0u, true); LDS_ATTR(P_STATIC_SPHERES, true, 0u, true); LDS_ATTR(P_STATIC_SPHERES, false, 0u, true);
 #undef LDS_ATTR
         if (ae != hipSuccess) { (void)hipGetLastError(); ds->lds_ok = false; }
       }

@@ -89,6 +89,7 @@ VARIANTS = [
     {"RTX_MOTION": "0"},                    # HEAD Book-1 on the reference's boxes (unions over the shutter) instead of the time-aware ones
     {"RTX_MOTION_TOPOLOGY": "0"},           # ... and its tree partitioned by those boxes instead of the mid-interval ones
     {"RTX_LEAF_FIRST": "0"},                # plain near-child-by-split-axis order everywhere
+    {"RTX_MOTION_AXIS": "0"},               # time-aware boxes with slopes for all three axes although only one moves (HEAD: y)
     {"RTX_SINGLE_LEAF": "0"},               # the general leaf loop on trees whose leaves all hold one primitive
     {"RTX_SINGLE_LEAF": "0", "RTX_RING": "0"},
 ]
